@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the fused skill-chaining step-batch on N MI355X (BASELINE.json metric).
+
+A "step" = one fused step-batch (scg_step: act + Pinball physics + option logic + Fourier features +
+Q + TD + weight update) over this rank's env shard, inputs resident in HBM. Workload = BASELINE
+configs[2]/[3]: 65 536 envs per GPU, full skill chain (5 options), independent env shards, no
+collective ("scaling": "weak"); --shared-weights switches to configs[4] (RCCL all-reduce of dW).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (td_kernel<FUSED>) from HIP events
+recorded on the launch stream inside libscg_hip.so; `cpu_baseline` times the in-repo CPU oracle (kind
+"port": the upstream reference ships no code to time) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+ENVS_PER_GPU = 65536
+N_OPTIONS = 5
+MAP = "pinball_simple"
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 vector
+BYTES_PER_ENV_STEP = 46         # SURVEY.md §8(d) algorithmic HBM bytes per env-step
+HP = dict(gamma=0.99, alpha=1e-3, epsilon=0.05, r_option_success=100.0, max_episode_steps=2000,
+          max_option_steps=250)
+
+
+def chain_discs(pmap, n_options):
+    """Synthetic skill chain standing in for discovered options: nested discs round the goal."""
+    import numpy as np
+    clf = np.zeros((n_options + 1, 8), np.float32)
+    tx, ty, _ = pmap.target
+    for k in range(1, n_options + 1):
+        r = 0.18 + 0.17 * (k - 1)
+        uc, vc, rr = 2 * tx - 1, 2 * ty - 1, 2 * r
+        clf[k, :6] = [rr * rr - uc * uc - vc * vc, 2 * uc, 2 * vc, -1.0, 0.0, -1.0]
+    return clf
+
+
+def flops_per_item(evaluated: bool, updated: bool) -> float:
+    """Algorithmic flops of one TD item: phi = 2 flop/feature (1 mul + 1 fma counted 3),
+    Q(s',.) 5 fma/feature, Q(s,a) 1 fma/feature, accumulate 1 fma/feature."""
+    f = 0.0
+    if evaluated:
+        f += 1296 * (3 + 10)
+    if updated:
+        f += 1296 * (3 + 2 + 2)
+    return f
+
+
+def cpu_baseline(seconds_target=15.0):
+    """Time the CPU oracle on a bounded sample of the same workload (same map, options, hyper-params)."""
+    import numpy as np
+    import sc_oracle
+    import skill_chaining_with_graphs_amd as scg
+    from skill_chaining_with_graphs_amd.core import fourier_scale_table
+    cores = min(os.cpu_count() or 1, 16)
+    n = 256 * cores                       # one 256-env block per thread
+    m = scg.load_map(MAP)
+    orc = sc_oracle.Oracle(m, fourier_scale_table(), n_envs=n, n_options=N_OPTIONS, seed=0,
+                           enabled_mask=sum(1 << k for k in range(1, N_OPTIONS + 1)), n_threads=cores, **HP)
+    clf = chain_discs(m, N_OPTIONS)
+    st = sc_oracle.new_state(n, m)
+    rng = np.random.default_rng(0)
+    pos = m.sample_free(n, rng)
+    st["x"][:], st["y"][:] = pos[:, 0], pos[:, 1]
+    v = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+    st["vx"][:], st["vy"][:] = v[0], v[1]
+    W = (rng.standard_normal((N_OPTIONS + 1, 5, 1296)) * 1e-3).astype(np.float32)
+    G, nk = orc.step(st, W, clf, 0)       # warm-up
+    orc.apply(W, G, nk)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds_target and steps < 1000:
+        G, nk = orc.step(st, W, clf, steps + 1)
+        orc.apply(W, G, nk)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, OpenMP over 256-env blocks), {n} envs x {steps} "
+                      f"step-batches of the same workload in {dt:.1f} s; the upstream reference ships no code to time"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--options", type=int, default=N_OPTIONS)
+    ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import skill_chaining_with_graphs_amd as scg
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_local = args.envs_per_gpu
+    n_opt = args.options
+    lo = rank * n_local
+    group = dist.group.WORLD if (distributed and args.shared_weights) else None
+    agent = SkillChainingAgent(MAP, n_local, n_opt, device=local_rank, seed=0, env_id_base=lo, group=group, **HP)
+    agent.clf.copy_(torch.as_tensor(chain_discs(agent.map, n_opt)))
+    for k in range(1, n_opt + 1):
+        agent.enable_option(k)
+    agent.init_weights(std=1e-3, seed=0)
+    agent.domain.reset_random(seed=1000 + rank, v_max=1.0)
+    lib, ctx = agent.ctx.lib, agent.ctx._ctx
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent.step_batch()
+    barrier()
+    lib.scg_profile_reset(ctx, 1)                 # HIP events round the fused kernel, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.step_batch()
+    barrier()
+    dt = time.perf_counter() - t0
+    import ctypes as C
+    k_ms, k_n = C.c_double(), C.c_int64()
+    lib.scg_profile_read(ctx, C.byref(k_ms), C.byref(k_n))
+    lib.scg_profile_reset(ctx, 0)
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    total_env_steps = float(n_local) * world * args.steps
+    value = total_env_steps / dt_max
+
+    out = None
+    if rank == 0:
+        kern_ms = k_ms.value / max(k_n.value, 1)
+        units = n_local
+        achieved = units * BYTES_PER_ENV_STEP / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node), 65536 parallel Pinball envs per MI355X, full skill chain",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n_local} envs/GPU x {world} GPU, map {MAP}, Fourier order 5 (1296 terms), "
+                                   f"root + {n_opt} chained options (synthetic nested-disc initiation sets), "
+                                   f"{'shared option-Q weights, RCCL all-reduce of dW' if group is not None else 'independent env shards, no collective'}",
+                       "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP},
+            "roofline": {"bound": "hbm", "kernel": "td_kernel<MODE_FUSED>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": kern_ms, "launches": int(k_n.value),
+                         "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+                         "note": "the fused kernel is fp32-VALU-bound, not HBM-bound (SURVEY.md §8d, DESIGN.md): "
+                                 "see `valu` for the binding roofline"},
+        }
+        # the binding (VALU) roofline: algorithmic flops of the TD items this rank processed per step
+        st = agent.state
+        opt = st.option_id.cpu().numpy()
+        n_opt_items = int((opt > 0).sum())
+        flops_step = units * flops_per_item(True, True) + n_opt_items * flops_per_item(True, True)
+        out["valu"] = {"bound": "valu_fp32", "achieved": flops_step / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                       "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": (flops_step / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS) if kern_ms > 0 else 0.0,
+                       "algorithmic_flop_per_step_batch": flops_step,
+                       "envs_in_an_option_at_end": n_opt_items}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * scg_abi.h — C-ABI of libscg_hip.so, the MI355X (gfx950) hot path of vectorized skill chaining.
+ *
+ * Reference interface replaced: BASELINE.json's north_star names PinballDomain.step,
+ * FourierBasis.features, Option.{policy,beta,initiation_classifier} and SkillChainingAgent.q_update,
+ * but the reference at /root/reference is README.md:1-2 only (title + one sentence naming Konidaris &
+ * Barto 2009) — it has no code, hence no FFI to bind and no file:line to cite for any entry point
+ * (SURVEY.md §0, §8a/b). The signatures below are therefore this build's own; each comment names the
+ * north_star symbol the entry point stands in for and the SPEC.md section that defines its arithmetic.
+ *
+ * Conventions
+ *  - plain C, no torch types. All array arguments are DEVICE pointers owned by the caller (e.g.
+ *    torch.Tensor.data_ptr()) unless marked HOST. `stream` is a hipStream_t passed as void*
+ *    (NULL = default stream). Launches are asynchronous on `stream`; nothing here synchronises.
+ *  - every function returns 0 on success or a negative scg_status; scg_last_error(ctx) gives text.
+ *    No exceptions cross the boundary.
+ *  - one ctx per (device, stream of use); calls on one ctx are not re-entrant. The library owns only
+ *    the ctx: map tables, the per-block partial-gradient slabs and the reduced gradient.
+ *  - state is SoA: x[N], y[N], vx[N], vy[N] float32.
+ */
+#ifndef SCG_ABI_H
+#define SCG_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCG_ABI_VERSION 1
+#define SCG_NUM_ACTIONS 5
+#define SCG_FOURIER_ORDER 5
+#define SCG_NUM_FEATURES 1296      /* (order+1)^4 */
+#define SCG_MAX_OPTIONS 5
+#define SCG_MAX_EDGES 256
+#define SCG_CLF_STRIDE 8           /* floats per classifier row (6 used) */
+#define SCG_BLOCK_ENVS 256         /* SPEC §5 reduction geometry */
+#define SCG_WAVES 8
+
+typedef enum {
+    SCG_OK = 0,
+    SCG_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    SCG_ERR_NO_DEVICE = -2,    /* no HIP device / wrong architecture */
+    SCG_ERR_HIP = -3,          /* a HIP runtime call failed */
+    SCG_ERR_STATE = -4         /* call order (e.g. step before set_map) */
+} scg_status;
+
+typedef struct scg_ctx scg_ctx;
+
+typedef struct {
+    int32_t n_envs;              /* envs on this rank */
+    int32_t n_options;           /* chained options 1..n_options (<= SCG_MAX_OPTIONS); VF 0 = root */
+    int32_t fourier_order;       /* must be SCG_FOURIER_ORDER */
+    int32_t device;              /* HIP device ordinal */
+    int64_t env_id_base;         /* global id of local env 0 (SPEC §2) */
+    uint64_t seed;
+    float gamma, alpha, epsilon, r_option_success;
+    int32_t max_episode_steps, max_option_steps;
+} scg_config;
+
+/* flags for scg_step */
+#define SCG_STEP_LEARN 1u        /* accumulate the TD gradient (otherwise act + physics + qcache only) */
+#define SCG_STEP_APPLY 2u        /* apply it to W in the same call (single-rank path) */
+
+int scg_abi_version(void);
+const char *scg_strerror(int status);
+const char *scg_last_error(const scg_ctx *ctx);
+
+int scg_create(scg_ctx **out, const scg_config *cfg);
+int scg_destroy(scg_ctx *ctx);
+/* change hyper-parameters between steps (n_envs / n_options / device are fixed at create) */
+int scg_set_hparams(scg_ctx *ctx, float gamma, float alpha, float epsilon, float r_option_success,
+                    int32_t max_episode_steps, int32_t max_option_steps);
+
+/* SPEC §1.1. All HOST pointers, copied. edges[n_edges][8], starts[n_starts][2], scale[1296].
+ * map_scalars = {R, hstep, R2, TX, TY, TR2}. */
+int scg_set_map(scg_ctx *ctx, const float *edges, int32_t n_edges, const float *starts, int32_t n_starts,
+                const float map_scalars[6], const float *scale);
+
+/* The fused step-batch: Option.policy (act from qcache) -> PinballDomain.step -> reset/bookkeeping ->
+ * Option.beta / option selection -> FourierBasis.features -> Q -> SkillChainingAgent.q_update
+ * (SPEC §1.3-§5). In/out: x,y,vx,vy, option_id, opt_steps, ep_steps, qcache[5][N].
+ * Out: action[N] u8, reward[N] f32, done[N] u8 (0 live, 1 goal, 2 time-limit).
+ * W[n_vf][5][1296] (updated iff SCG_STEP_APPLY), clf[n_vf][8] (row 0 unused), enabled bit k = option k.
+ * t = step counter (RNG key). */
+int scg_step(scg_ctx *ctx, float *x, float *y, float *vx, float *vy, int32_t *option_id,
+             int32_t *opt_steps, int32_t *ep_steps, float *qcache, uint8_t *action, float *reward,
+             uint8_t *done, float *W, const float *clf, uint32_t enabled_mask, uint64_t t,
+             uint32_t flags, void *stream);
+
+/* Device pointers of the ctx-owned reduced gradient G[n_vf][5][1296] and counts n_k[n_vf] (int32)
+ * left by the last scg_step(LEARN) — the buffers a multi-rank caller all-reduces (SPEC §5). */
+int scg_grad_buffers(scg_ctx *ctx, float **G, int32_t **n_k);
+/* Make scg_step / scg_q_update leave G and n_k in caller-owned device buffers instead
+ * (G[n_vf][5][1296] float32, n_k[n_vf] int32); NULL, NULL restores the ctx-owned ones. */
+int scg_set_grad_buffers(scg_ctx *ctx, float *G, int32_t *n_k);
+/* Apply (possibly all-reduced) G / n_k to W: W_k += alpha/n_k * scale * G_k (SPEC §5). */
+int scg_apply_update(scg_ctx *ctx, float *W, const float *G, const int32_t *n_k, void *stream);
+
+/* ---- un-fused entry points (same arithmetic; used by the API facade and the parity tests) ---- */
+
+/* PinballDomain.step (SPEC §1.3) with caller-given actions; no reset. goal[n] u8. */
+int scg_pinball_step(scg_ctx *ctx, int32_t n, float *x, float *y, float *vx, float *vy,
+                     const uint8_t *action, float *reward, uint8_t *goal, void *stream);
+/* FourierBasis.features (SPEC §3): phi[n][1296]. */
+int scg_fourier_features(scg_ctx *ctx, int32_t n, const float *x, const float *y, const float *vx,
+                         const float *vy, float *phi, void *stream);
+/* Option.policy value part (SPEC §3.1): q[5][n] = Q_k(s, .) for one VF Wk[5][1296]. */
+int scg_q_values(scg_ctx *ctx, int32_t n, const float *x, const float *y, const float *vx,
+                 const float *vy, const float *Wk, float *q, void *stream);
+/* SkillChainingAgent.q_update on explicit transitions for one VF (SPEC §5): accumulates G_k and n_k
+ * into the ctx gradient buffers at VF index k (other VFs zeroed), optionally applies to Wk_all. */
+int scg_q_update(scg_ctx *ctx, int32_t n, int32_t k, const float *x, const float *y, const float *vx,
+                 const float *vy, const uint8_t *action, const float *r, const float *cont,
+                 const float *xn, const float *yn, const float *vxn, const float *vyn, float *W,
+                 uint32_t flags, void *stream);
+/* Option.initiation_classifier.predict (SPEC §4.1): out[n] u8 = w.psi(x,y) > 0 for one row w8[8]. */
+int scg_classifier_predict(scg_ctx *ctx, int32_t n, const float *x, const float *y, const float *w8,
+                           uint8_t *out, void *stream);
+/* Option.initiation_classifier.fit (SPEC §6), batched over n_fit options: xy[M_total][2],
+ * label[M_total] u8, offsets[n_fit+1] int32 (device), w[n_fit][8] in/out. */
+int scg_fit_initiation(scg_ctx *ctx, int32_t n_fit, const float *xy, const uint8_t *label,
+                       const int32_t *offsets, float *w, int32_t iters, float lr, float l2, void *stream);
+
+/* ---- measurement hooks (bench.py's roofline leg) ----
+ * scg_profile_reset(ctx, 1) makes every following scg_step record a HIP event pair round its fused
+ * kernel on the launch stream; scg_profile_read synchronises those events and returns the summed
+ * kernel time (ms) and the number of launches measured; scg_profile_reset(ctx, 0) stops recording. */
+int scg_profile_reset(scg_ctx *ctx, int32_t enable);
+int scg_profile_read(scg_ctx *ctx, double *kernel_ms_sum, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

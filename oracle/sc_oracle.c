@@ -1,0 +1,515 @@
+/*
+ * sc_oracle.c — scalar CPU restatement of SPEC.md. TEST INFRASTRUCTURE, NOT PRODUCT; PARITY UNPINNED
+ * (see sc_oracle.h: the upstream reference is README.md:1-2 only, there is nothing to follow or cite
+ * beyond the paper title; every function below cites the SPEC.md section it implements).
+ *
+ * Build: gcc -O2 -std=c11 -ffp-contract=off -mfma -fopenmp -fPIC -shared (oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: fusion happens only where fmaf() is written.
+ */
+#include "sc_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NACT SCO_NACT
+#define NF SCO_NF
+#define NLANE 64
+#define NSLOT 21
+
+/* ------------------------------------------------------------------ SPEC §2: Philox4x32-10 */
+void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+/* ------------------------------------------------------------------ SPEC §3: sincospi, cmul */
+void sco_sincospi(float t, float *c, float *s) {
+    const float S0 = 0x1.921fb6p+1f, S1 = -0x1.4abbcep+2f, S2 = 0x1.466bc6p+1f, S3 = -0x1.32d2ccp-1f,
+                S4 = 0x1.507834p-4f;
+    const float C0 = -0x1.3bd3ccp+2f, C1 = 0x1.03c1f0p+2f, C2 = -0x1.55d3c8p+0f, C3 = 0x1.e1f506p-3f,
+                C4 = -0x1.a6d1f2p-6f;
+    float n = rintf(t + t);
+    float r = fmaf(n, -0.5f, t);
+    float z = r * r;
+    float sp = fmaf(z, S4, S3); sp = fmaf(z, sp, S2); sp = fmaf(z, sp, S1); sp = fmaf(z, sp, S0); sp = sp * r;
+    float cp = fmaf(z, C4, C3); cp = fmaf(z, cp, C2); cp = fmaf(z, cp, C1); cp = fmaf(z, cp, C0);
+    cp = fmaf(z, cp, 1.0f);
+    int q = (int)n & 3;
+    switch (q) {
+        case 0: *c = cp; *s = sp; break;
+        case 1: *c = -sp; *s = cp; break;
+        case 2: *c = -cp; *s = -sp; break;
+        default: *c = sp; *s = -cp; break;
+    }
+}
+
+typedef struct { float re, im; } cplx;
+static inline cplx cmul(cplx a, cplx b) {
+    cplx o;
+    o.re = fmaf(-a.im, b.im, a.re * b.re);
+    o.im = fmaf(a.re, b.im, a.im * b.re);
+    return o;
+}
+
+/* AB[36], CD[36] of one state (SPEC §3) */
+static void state_tables(float x, float y, float vx, float vy, cplx AB[36], cplx CD[36]) {
+    float sh[4] = {x, y, fmaf(vx, 0.25f, 0.5f), fmaf(vy, 0.25f, 0.5f)};
+    cplx Z[4][6];
+    for (int d = 0; d < 4; ++d) {
+        Z[d][0].re = 1.0f; Z[d][0].im = 0.0f;
+        sco_sincospi(sh[d], &Z[d][1].re, &Z[d][1].im);
+        for (int k = 2; k < 6; ++k) Z[d][k] = cmul(Z[d][k - 1], Z[d][1]);
+    }
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+            AB[a * 6 + b] = cmul(Z[0][a], Z[1][b]);
+            CD[a * 6 + b] = cmul(Z[2][a], Z[3][b]);
+        }
+}
+
+static void state_features(float x, float y, float vx, float vy, float *phi) {
+    cplx AB[36], CD[36];
+    state_tables(x, y, vx, vy, AB, CD);
+    for (int c12 = 0; c12 < 36; ++c12)
+        for (int c34 = 0; c34 < 36; ++c34)
+            phi[c12 * 36 + c34] = fmaf(-AB[c12].im, CD[c34].im, AB[c12].re * CD[c34].re);
+}
+
+/* ------------------------------------------------------------------ SPEC §3.1: canonical wave order */
+int sco_feature_index(int lane, int slot) {
+    if (lane < 0 || lane >= NLANE || slot < 0 || slot >= NSLOT) return -1;
+    if (slot < 18) return (2 * slot + (lane >> 5)) * 36 + (lane & 31);
+    int idx = 64 * (slot - 18) + lane;
+    if (idx >= 144) return -1;
+    return (idx >> 2) * 36 + 32 + (idx & 3);
+}
+
+static int g_order[NLANE][NSLOT];
+static int g_order_ready = 0;
+static void init_order(void) {
+    if (g_order_ready) return;
+    for (int l = 0; l < NLANE; ++l)
+        for (int j = 0; j < NSLOT; ++j) g_order[l][j] = sco_feature_index(l, j);
+    g_order_ready = 1;
+}
+
+static float wave_dot(const float *w, const float *phi) {
+    float p[NLANE];
+    for (int l = 0; l < NLANE; ++l) {
+        float acc = 0.0f;
+        for (int j = 0; j < NSLOT; ++j) {
+            int f = g_order[l][j];
+            if (f >= 0) acc = fmaf(w[f], phi[f], acc);
+        }
+        p[l] = acc;
+    }
+    for (int m = 1; m < NLANE; m <<= 1) {
+        float q[NLANE];
+        for (int l = 0; l < NLANE; ++l) q[l] = p[l] + p[l ^ m];
+        memcpy(p, q, sizeof p);
+    }
+    return p[0];
+}
+
+/* ------------------------------------------------------------------ SPEC §1.3: physics */
+static int intercept(const float *E, float R2, float x, float y, float vx, float vy) {
+    const float KAPPA2 = 0x1.0553bep-14f;
+    float x0 = E[0], y0 = E[1], ex = E[2], ey = E[3], inv = E[4];
+    float dx = x - x0, dy = y - y0;
+    float t = fmaf(dy, ey, dx * ex) * inv;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    float cx = fmaf(ex, t, x0), cy = fmaf(ey, t, y0);
+    float bx = cx - x, by = cy - y;
+    float d2 = fmaf(by, by, bx * bx);
+    if (d2 > R2) return 0;
+    float dot = fmaf(by, vy, bx * vx);
+    if (dot >= 0.0f) return 1;
+    float vv = fmaf(vy, vy, vx * vx);
+    return dot * dot <= (KAPPA2 * d2) * vv;
+}
+
+static void pinball_step1(const sco_params *p, float *px, float *py, float *pvx, float *pvy, int a,
+                          float *reward, int *goal_out) {
+    const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
+    float x = *px, y = *py, vx = *pvx, vy = *pvy;
+    const float h = p->hstep;
+    if (a == 0) vx = vx + DV;
+    else if (a == 2) vx = vx - DV;
+    else if (a == 1) vy = vy + DV;
+    else if (a == 3) vy = vy - DV;
+    vx = fminf(fmaxf(vx, -VMAX), VMAX);
+    vy = fminf(fmaxf(vy, -VMAX), VMAX);
+    int goal = 0;
+    for (int i = 0; i < 20; ++i) {
+        x = fmaf(vx, h, x); y = fmaf(vy, h, y);
+        int nhit = 0, first = -1;
+        for (int j = 0; j < p->n_edges; ++j)
+            if (intercept(p->edges + 8 * j, p->r2, x, y, vx, vy)) {
+                if (nhit == 0) first = j;
+                ++nhit;
+            }
+        if (nhit == 1) {
+            const float *E = p->edges + 8 * first;
+            float ux = E[5], uy = E[6];
+            float pr = fmaf(vy, uy, vx * ux);
+            float tp = pr + pr;
+            float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
+            vx = nvx; vy = nvy;
+            if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
+        } else if (nhit > 1) {
+            vx = -vx; vy = -vy;
+        }
+        float gx = x - p->tx, gy = y - p->ty;
+        if (fmaf(gy, gy, gx * gx) < p->tr2) { goal = 1; break; }
+    }
+    if (goal) {
+        *reward = 10000.0f;
+    } else {
+        vx = vx * DRAG; vy = vy * DRAG;
+        x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f);
+        *reward = (a == 4) ? -1.0f : -5.0f;
+    }
+    *px = x; *py = y; *pvx = vx; *pvy = vy; *goal_out = goal;
+}
+
+void sco_pinball_step(const sco_params *p, int n, float *x, float *y, float *vx, float *vy,
+                      const uint8_t *action, float *reward, uint8_t *goal) {
+    for (int e = 0; e < n; ++e) {
+        int g;
+        pinball_step1(p, &x[e], &y[e], &vx[e], &vy[e], action[e], &reward[e], &g);
+        goal[e] = (uint8_t)g;
+    }
+}
+
+void sco_features(int n, const float *x, const float *y, const float *vx, const float *vy, float *phi) {
+    for (int e = 0; e < n; ++e) state_features(x[e], y[e], vx[e], vy[e], phi + (size_t)e * NF);
+}
+
+void sco_q_values(int n, const float *x, const float *y, const float *vx, const float *vy,
+                  const float *Wk, float *q) {
+    init_order();
+    float *phi = (float *)malloc(sizeof(float) * NF);
+    for (int e = 0; e < n; ++e) {
+        state_features(x[e], y[e], vx[e], vy[e], phi);
+        for (int a = 0; a < NACT; ++a) q[(size_t)a * n + e] = wave_dot(Wk + a * NF, phi);
+    }
+    free(phi);
+}
+
+/* ------------------------------------------------------------------ SPEC §4.1: classifier */
+static float clf_z(const float *w, float x, float y) {
+    float u = fmaf(x, 2.0f, -1.0f), v = fmaf(y, 2.0f, -1.0f);
+    float z = w[0];
+    z = fmaf(w[1], u, z); z = fmaf(w[2], v, z);
+    z = fmaf(w[3], u * u, z); z = fmaf(w[4], u * v, z); z = fmaf(w[5], v * v, z);
+    return z;
+}
+
+void sco_classifier_predict(int n, const float *x, const float *y, const float *w8, uint8_t *out) {
+    for (int e = 0; e < n; ++e) out[e] = clf_z(w8, x[e], y[e]) > 0.0f;
+}
+
+static int in_set(const sco_params *p, const float *clf, int k, float x, float y) {
+    if (k < 1 || k > p->n_options) return 0;
+    if (!((p->enabled_mask >> k) & 1u)) return 0;
+    return clf_z(clf + SCO_CLF_STRIDE * k, x, y) > 0.0f;
+}
+
+/* ------------------------------------------------------------------ SPEC §5: block TD machinery */
+typedef struct {
+    float s[4], sn[4];
+    int a;
+    /* per VF flags for this env, filled by the caller */
+} env_rec;
+
+/* One (block, VF) pass. items: indices into the block (0..nb-1) in env order with flags.
+ * phi_s / phi_n: [nb][1296] feature rows of s and s_next (computed lazily by the caller).
+ * Adds the block partial P_b,k into Pout[5][1296] (overwrites). */
+typedef struct {
+    int env;      /* block-local env index */
+    int upd, tgt, cache;
+    float r, cont;
+} td_item;
+
+static void block_vf_pass(const float *Wk, int n_items, const td_item *items, const env_rec *rec,
+                          const float *phi_s, const float *phi_n, float *qcache, int qstride,
+                          int env0, float *Pout, int *n_upd) {
+    /* acc[wave][a][f] */
+    float *acc = (float *)calloc((size_t)SCO_WAVES * NACT * NF, sizeof(float));
+    int cnt = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const td_item *it = &items[i];
+        int w = i % SCO_WAVES;
+        const env_rec *r = &rec[it->env];
+        float qn[NACT] = {0, 0, 0, 0, 0};
+        if (it->tgt || it->cache) {
+            const float *pn = phi_n + (size_t)it->env * NF;
+            for (int a = 0; a < NACT; ++a) qn[a] = wave_dot(Wk + a * NF, pn);
+            if (it->cache)
+                for (int a = 0; a < NACT; ++a) qcache[(size_t)a * qstride + env0 + it->env] = qn[a];
+        }
+        if (it->upd) {
+            const float *ps = phi_s + (size_t)it->env * NF;
+            float qsa = wave_dot(Wk + r->a * NF, ps);
+            float m = qn[0];
+            for (int a = 1; a < NACT; ++a) m = fmaxf(m, qn[a]);
+            float target = it->tgt ? fmaf(it->cont, m, it->r) : it->r;
+            float delta = target - qsa;
+            float *dst = acc + ((size_t)w * NACT + r->a) * NF;
+            for (int f = 0; f < NF; ++f) dst[f] = fmaf(delta, ps[f], dst[f]);
+            ++cnt;
+        }
+    }
+    for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
+        float s = acc[i];
+        for (int w = 1; w < SCO_WAVES; ++w) s = s + acc[(size_t)w * NACT * NF + i];
+        Pout[i] = s;
+    }
+    free(acc);
+    *n_upd = cnt;
+}
+
+int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint8_t *action,
+                      const float *r, const float *cont, const float *sn4[4], const float *Wk, float *G) {
+    init_order();
+    int nblk = (n + SCO_BLOCK_ENVS - 1) / SCO_BLOCK_ENVS;
+    float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * NACT * NF);
+    int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1), sizeof(int));
+    int nthreads = p && p->n_threads > 0 ? p->n_threads : 1;
+    (void)nthreads;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int b = 0; b < nblk; ++b) {
+        int e0 = b * SCO_BLOCK_ENVS;
+        int nb = n - e0 < SCO_BLOCK_ENVS ? n - e0 : SCO_BLOCK_ENVS;
+        env_rec *rec = (env_rec *)malloc(sizeof(env_rec) * nb);
+        td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
+        float *phi_s = (float *)malloc(sizeof(float) * (size_t)nb * NF);
+        float *phi_n = (float *)malloc(sizeof(float) * (size_t)nb * NF);
+        float dummy_q[NACT];
+        for (int i = 0; i < nb; ++i) {
+            int e = e0 + i;
+            for (int d = 0; d < 4; ++d) { rec[i].s[d] = s4[d][e]; rec[i].sn[d] = sn4[d][e]; }
+            rec[i].a = action[e];
+            items[i].env = i; items[i].upd = 1; items[i].tgt = cont[e] > 0.0f; items[i].cache = 0;
+            items[i].r = r[e]; items[i].cont = cont[e];
+            state_features(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], phi_s + (size_t)i * NF);
+            if (items[i].tgt)
+                state_features(rec[i].sn[0], rec[i].sn[1], rec[i].sn[2], rec[i].sn[3], phi_n + (size_t)i * NF);
+        }
+        block_vf_pass(Wk, nb, items, rec, phi_s, phi_n, dummy_q, 0, 0, P + (size_t)b * NACT * NF, &cnts[b]);
+        free(rec); free(items); free(phi_s); free(phi_n);
+    }
+    int total = 0;
+    for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
+        float s = nblk > 0 ? P[i] : 0.0f;
+        for (int b = 1; b < nblk; ++b) s = s + P[(size_t)b * NACT * NF + i];
+        G[i] = s;
+    }
+    for (int b = 0; b < nblk; ++b) total += cnts[b];
+    free(P); free(cnts);
+    return total;
+}
+
+void sco_apply(const sco_params *p, int n_vf, float *W, const float *G, const int32_t *n_k) {
+    for (int k = 0; k < n_vf; ++k) {
+        if (n_k[k] <= 0) continue;
+        float step = p->alpha / (float)n_k[k];
+        for (int a = 0; a < NACT; ++a)
+            for (int f = 0; f < NF; ++f) {
+                size_t i = ((size_t)k * NACT + a) * NF + f;
+                W[i] = fmaf(step * p->scale[f], G[i], W[i]);
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ SPEC §1.4, §2, §4, §5: step-batch */
+void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int32_t *option_id,
+              int32_t *opt_steps, int32_t *ep_steps, float *qcache, uint8_t *action, float *reward,
+              uint8_t *done, const float *W, const float *clf, uint64_t t, float *G, int32_t *n_k) {
+    init_order();
+    const int N = p->n_envs;
+    const int n_vf = p->n_options + 1;
+    const int nblk = (N + SCO_BLOCK_ENVS - 1) / SCO_BLOCK_ENVS;
+    float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * n_vf * NACT * NF);
+    int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1) * n_vf, sizeof(int));
+    int nthreads = p->n_threads > 0 ? p->n_threads : 1;
+    (void)nthreads;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int b = 0; b < nblk; ++b) {
+        int e0 = b * SCO_BLOCK_ENVS;
+        int nb = N - e0 < SCO_BLOCK_ENVS ? N - e0 : SCO_BLOCK_ENVS;
+        env_rec rec[SCO_BLOCK_ENVS];
+        int o_t[SCO_BLOCK_ENVS], o_n[SCO_BLOCK_ENVS];
+        float r0[SCO_BLOCK_ENVS], c0[SCO_BLOCK_ENVS], ro[SCO_BLOCK_ENVS], co[SCO_BLOCK_ENVS];
+        float *phi_s = (float *)malloc(sizeof(float) * (size_t)nb * NF);
+        float *phi_n = (float *)malloc(sizeof(float) * (size_t)nb * NF);
+        td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
+        /* ---- phase P: act, physics, bookkeeping, option logic (per env) */
+        for (int i = 0; i < nb; ++i) {
+            int e = e0 + i;
+            uint64_t g = (uint64_t)(p->env_id_base + e);
+            uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(t & 0xffffffffu), (uint32_t)(t >> 32), 0u};
+            uint32_t key[2] = {(uint32_t)(p->seed & 0xffffffffu), (uint32_t)(p->seed >> 32)};
+            uint32_t u[4];
+            sco_philox4x32_10(ctr, key, u);
+            int explore = (float)(u[0] >> 8) * 0x1p-24f < p->epsilon;
+            int a_rand = (int)mulhi32(u[1], 5u);
+            int a_greedy = 0;
+            float best = qcache[e];
+            for (int a = 1; a < NACT; ++a) {
+                float q = qcache[(size_t)a * N + e];
+                if (q > best) { best = q; a_greedy = a; }
+            }
+            int a = explore ? a_rand : a_greedy;
+            float sx = x[e], sy = y[e], svx = vx[e], svy = vy[e];
+            rec[i].s[0] = sx; rec[i].s[1] = sy; rec[i].s[2] = svx; rec[i].s[3] = svy;
+            rec[i].a = a;
+            float rew; int goal;
+            pinball_step1(p, &sx, &sy, &svx, &svy, a, &rew, &goal);
+            int eps1 = ep_steps[e] + 1;
+            int timeout = !goal && eps1 >= p->max_episode_steps;
+            int dn = goal ? 1 : (timeout ? 2 : 0);
+            float nx = sx, ny = sy, nvx = svx, nvy = svy;
+            if (dn) {
+                uint32_t si = mulhi32(u[2], (uint32_t)p->n_starts);
+                nx = p->starts[2 * si]; ny = p->starts[2 * si + 1]; nvx = 0.0f; nvy = 0.0f;
+            }
+            rec[i].sn[0] = nx; rec[i].sn[1] = ny; rec[i].sn[2] = nvx; rec[i].sn[3] = nvy;
+            int o = option_id[e];
+            int keep = 0;
+            ro[i] = 0.0f; co[i] = 0.0f;
+            if (o >= 1) {
+                int succ = (o == 1) ? goal : in_set(p, clf, o - 1, sx, sy);
+                int fail = !succ && !in_set(p, clf, o, sx, sy);
+                int otime = opt_steps[e] + 1 >= p->max_option_steps;
+                int term = (dn != 0) || succ || fail || otime;
+                ro[i] = rew + (succ ? p->r_option_success : 0.0f);
+                co[i] = term ? 0.0f : p->gamma;
+                keep = !term;
+            }
+            int on = 0;
+            if (keep) on = o;
+            else
+                for (int k = 1; k <= p->n_options; ++k) {
+                    if (!in_set(p, clf, k, nx, ny)) continue;
+                    if (k >= 2 && in_set(p, clf, k - 1, nx, ny)) continue;
+                    on = k; break;
+                }
+            o_t[i] = o; o_n[i] = on;
+            r0[i] = rew; c0[i] = dn ? 0.0f : p->gamma;
+            /* outputs */
+            action[e] = (uint8_t)a; reward[e] = rew; done[e] = (uint8_t)dn;
+            x[e] = nx; y[e] = ny; vx[e] = nvx; vy[e] = nvy;
+            option_id[e] = on;
+            opt_steps[e] = keep ? opt_steps[e] + 1 : 0;
+            ep_steps[e] = dn ? 0 : eps1;
+            state_features(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], phi_s + (size_t)i * NF);
+            state_features(nx, ny, nvx, nvy, phi_n + (size_t)i * NF);
+        }
+        /* ---- TD passes, VF by VF */
+        for (int k = 0; k < n_vf; ++k) {
+            int m = 0;
+            for (int i = 0; i < nb; ++i) {
+                int upd = (k == 0) || (o_t[i] == k);
+                int cache = (o_n[i] == k);
+                if (!upd && !cache) continue;
+                float cont = (k == 0) ? c0[i] : co[i];
+                items[m].env = i; items[m].upd = upd; items[m].cache = cache;
+                items[m].tgt = upd && cont > 0.0f;
+                items[m].r = (k == 0) ? r0[i] : ro[i];
+                items[m].cont = cont;
+                ++m;
+            }
+            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, phi_s, phi_n, qcache, N, e0,
+                          P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k]);
+        }
+        free(phi_s); free(phi_n); free(items);
+    }
+    for (int k = 0; k < n_vf; ++k) {
+        for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
+            float s = nblk > 0 ? P[(size_t)k * NACT * NF + i] : 0.0f;
+            for (int b = 1; b < nblk; ++b) s = s + P[((size_t)b * n_vf + k) * NACT * NF + i];
+            G[(size_t)k * NACT * NF + i] = s;
+        }
+        int tot = 0;
+        for (int b = 0; b < nblk; ++b) tot += cnts[(size_t)b * n_vf + k];
+        n_k[k] = tot;
+    }
+    free(P); free(cnts);
+}
+
+/* ------------------------------------------------------------------ SPEC §6: logistic regression */
+float sco_sigmoid(float z) {
+    const float LOG2E = 0x1.715476p+0f, LN2HI = 0x1.63p-1f, LN2LO = -0x1.bd0106p-13f;
+    const float E2 = 0x1p-1f, E3 = 0x1.555556p-3f, E4 = 0x1.555556p-5f, E5 = 0x1.111112p-7f,
+                E6 = 0x1.6c16c2p-10f, E7 = 0x1.a01a02p-13f;
+    float a = -fabsf(z);
+    a = fmaxf(a, -87.0f);
+    float n = rintf(a * LOG2E);
+    float r = fmaf(n, -LN2HI, a);
+    r = fmaf(n, -LN2LO, r);
+    float pl = E7;
+    pl = fmaf(pl, r, E6); pl = fmaf(pl, r, E5); pl = fmaf(pl, r, E4); pl = fmaf(pl, r, E3);
+    pl = fmaf(pl, r, E2); pl = fmaf(pl, r, 1.0f); pl = fmaf(pl, r, 1.0f);
+    union { uint32_t u; float f; } sc;
+    sc.u = (uint32_t)((int)n + 127) << 23;
+    float e = pl * sc.f;
+    return z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+}
+
+void sco_fit_initiation(int n_fit, const float *xy, const uint8_t *label, const int32_t *offsets,
+                        float *w, int iters, float lr, float l2) {
+    enum { T = 256 };
+    for (int q = 0; q < n_fit; ++q) {
+        float *wq = w + SCO_CLF_STRIDE * q;
+        int i0 = offsets[q], M = offsets[q + 1] - offsets[q];
+        if (M <= 0) continue;
+        float invM = 1.0f / (float)M;
+        for (int it = 0; it < iters; ++it) {
+            float part[T][6];
+            for (int tau = 0; tau < T; ++tau) {
+                float g[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = tau; i < M; i += T) {
+                    float xx = xy[2 * (size_t)(i0 + i)], yy = xy[2 * (size_t)(i0 + i) + 1];
+                    float u = fmaf(xx, 2.0f, -1.0f), v = fmaf(yy, 2.0f, -1.0f);
+                    float psi[6] = {1.0f, u, v, u * u, u * v, v * v};
+                    float z = clf_z(wq, xx, yy);
+                    float e = sco_sigmoid(z) - (float)label[i0 + i];
+                    for (int j = 0; j < 6; ++j) g[j] = fmaf(e, psi[j], g[j]);
+                }
+                for (int j = 0; j < 6; ++j) part[tau][j] = g[j];
+            }
+            for (int j = 0; j < 6; ++j) {
+                float wave_sum[4];
+                for (int wv = 0; wv < 4; ++wv) {
+                    float pbuf[64], qbuf[64];
+                    for (int l = 0; l < 64; ++l) pbuf[l] = part[wv * 64 + l][j];
+                    for (int m = 1; m < 64; m <<= 1) {
+                        for (int l = 0; l < 64; ++l) qbuf[l] = pbuf[l] + pbuf[l ^ m];
+                        memcpy(pbuf, qbuf, sizeof pbuf);
+                    }
+                    wave_sum[wv] = pbuf[0];
+                }
+                float g = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
+                float reg = (j > 0) ? l2 * wq[j] : 0.0f;
+                wq[j] = wq[j] - lr * ((g * invM) + reg);
+            }
+        }
+    }
+}

@@ -1,0 +1,74 @@
+/*
+ * sc_oracle.h — scalar CPU restatement of SPEC.md (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * PARITY UNPINNED: the upstream reference (/root/reference) holds only README.md:1-2 (a title and one
+ * sentence naming Konidaris & Barto 2009); it has no code, tests, fixtures or golden vectors, so
+ * nothing here can be checked against it. This oracle follows this repo's own
+ * SPEC.md and is pinned only by the hand-computed known-answer tests in tests/ and the published
+ * Philox4x32-10 vectors. It may be imported/linked only by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg. The product (skill-chaining-with-graphs_amd/) never touches it.
+ */
+#ifndef SC_ORACLE_H
+#define SC_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCO_NACT 5
+#define SCO_NF 1296
+#define SCO_BLOCK_ENVS 256
+#define SCO_WAVES 8
+#define SCO_CLF_STRIDE 8
+
+typedef struct {
+    int32_t n_envs;
+    int32_t n_options;          /* chained options 1..n_options; VF 0 = root */
+    int64_t env_id_base;
+    uint64_t seed;
+    float gamma, alpha, epsilon, r_option_success;
+    int32_t max_episode_steps, max_option_steps;
+    uint32_t enabled_mask;      /* bit k = option k usable */
+    int32_t n_threads;          /* OpenMP threads for the block loop (1 = scalar) */
+    /* map (SPEC §1.1) */
+    int32_t n_edges;
+    int32_t n_starts;
+    const float *edges;         /* [n_edges][8] x0,y0,ex,ey,inv_len2,ux,uy,pad */
+    const float *starts;        /* [n_starts][2] */
+    float radius, hstep, r2, tx, ty, tr2;
+    const float *scale;         /* [1296] 1/||c|| */
+} sco_params;
+
+void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void sco_sincospi(float t, float *c, float *s);
+float sco_sigmoid(float z);
+int sco_feature_index(int lane, int slot);   /* canonical wave order, -1 if the slot is empty */
+
+/* SPEC §1.3 for n independent envs with given actions; no reset, no bookkeeping. */
+void sco_pinball_step(const sco_params *p, int n, float *x, float *y, float *vx, float *vy,
+                      const uint8_t *action, float *reward, uint8_t *goal);
+/* SPEC §3: phi[n][1296] */
+void sco_features(int n, const float *x, const float *y, const float *vx, const float *vy, float *phi);
+/* SPEC §3.1: q[5][n] for one VF (W_k = [5][1296]) */
+void sco_q_values(int n, const float *x, const float *y, const float *vx, const float *vy,
+                  const float *Wk, float *q);
+/* SPEC §4.1 */
+void sco_classifier_predict(int n, const float *x, const float *y, const float *w8, uint8_t *out);
+/* SPEC §5 for one VF on explicit transitions (all items upd, none cache); G[5][1296], returns n_k. */
+int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint8_t *action,
+                      const float *r, const float *cont, const float *sn4[4], const float *Wk, float *G);
+/* SPEC §5 apply for n_vf value functions. */
+void sco_apply(const sco_params *p, int n_vf, float *W, const float *G, const int32_t *n_k);
+/* SPEC §1.4, §2, §4, §5: one step-batch. G[n_vf][5][1296] and n_k[n_vf] are outputs; W is not modified. */
+void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int32_t *option_id,
+              int32_t *opt_steps, int32_t *ep_steps, float *qcache, uint8_t *action, float *reward,
+              uint8_t *done, const float *W, const float *clf, uint64_t t, float *G, int32_t *n_k);
+/* SPEC §6: n_fit problems; offsets[n_fit+1] index xy/label; w[n_fit][8] in/out. */
+void sco_fit_initiation(int n_fit, const float *xy, const uint8_t *label, const int32_t *offsets,
+                        float *w, int iters, float lr, float l2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

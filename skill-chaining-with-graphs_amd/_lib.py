@@ -1,0 +1,99 @@
+"""ctypes binding of libscg_hip.so (include/scg_abi.h). The product path has NO fallback: if the HIP
+library is missing or a call fails, this module raises — it never routes to a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libscg_hip.so")
+
+NUM_ACTIONS = 5
+FOURIER_ORDER = 5
+NUM_FEATURES = 1296
+MAX_OPTIONS = 5
+MAX_EDGES = 256
+CLF_STRIDE = 8
+BLOCK_ENVS = 256
+WAVES = 8
+
+STEP_LEARN = 1
+STEP_APPLY = 2
+
+
+class ScgError(RuntimeError):
+    pass
+
+
+class ScgConfig(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32),
+        ("n_options", C.c_int32),
+        ("fourier_order", C.c_int32),
+        ("device", C.c_int32),
+        ("env_id_base", C.c_int64),
+        ("seed", C.c_uint64),
+        ("gamma", C.c_float),
+        ("alpha", C.c_float),
+        ("epsilon", C.c_float),
+        ("r_option_success", C.c_float),
+        ("max_episode_steps", C.c_int32),
+        ("max_option_steps", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "scg_abi_version": (C.c_int, []),
+    "scg_strerror": (C.c_char_p, [C.c_int]),
+    "scg_last_error": (C.c_char_p, [_P]),
+    "scg_create": (C.c_int, [C.POINTER(_P), C.POINTER(ScgConfig)]),
+    "scg_destroy": (C.c_int, [_P]),
+    "scg_set_hparams": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
+    "scg_set_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P]),
+    "scg_step": (C.c_int, [_P] + [_P] * 13 + [C.c_uint32, C.c_uint64, C.c_uint32, _P]),
+    "scg_grad_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "scg_set_grad_buffers": (C.c_int, [_P, _P, _P]),
+    "scg_apply_update": (C.c_int, [_P, _P, _P, _P, _P]),
+    "scg_pinball_step": (C.c_int, [_P, C.c_int32] + [_P] * 7 + [_P]),
+    "scg_fourier_features": (C.c_int, [_P, C.c_int32] + [_P] * 5 + [_P]),
+    "scg_q_values": (C.c_int, [_P, C.c_int32] + [_P] * 6 + [_P]),
+    "scg_q_update": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 12 + [C.c_uint32, _P]),
+    "scg_classifier_predict": (C.c_int, [_P, C.c_int32] + [_P] * 4 + [_P]),
+    "scg_profile_reset": (C.c_int, [_P, C.c_int32]),
+    "scg_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "scg_fit_initiation": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libscg_hip.so (once). Raises ScgError loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScgError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
+            f"{os.path.dirname(LIB_PATH)}`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.scg_abi_version() != 1:
+        raise ScgError("libscg_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, ctx=None, what: str = "") -> None:
+    if status == 0:
+        return
+    lib = load()
+    msg = lib.scg_last_error(ctx).decode() if True else ""
+    raise ScgError(f"{what or 'scg call'} failed ({lib.scg_strerror(status).decode()}): {msg}")

@@ -1,0 +1,215 @@
+"""ScgContext — thin, checked Python wrapper over the C-ABI (include/scg_abi.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation happens in the HIP
+kernels behind libscg_hip.so. Operand shapes/dtypes/devices are validated on the host before any
+launch (a kernel fault can take the whole GPU host down)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (CLF_STRIDE, MAX_OPTIONS, NUM_ACTIONS, NUM_FEATURES, STEP_APPLY, STEP_LEARN, ScgConfig,
+                   ScgError)
+from .maps import PinballMap
+
+
+def fourier_scale_table(order: int = 5, n_vars: int = 4) -> np.ndarray:
+    """SPEC §3: scale_f = 1/||c||_2 (1 for c = 0), float64 then rounded; canonical feature order."""
+    n = order + 1
+    idx = np.arange(n ** n_vars)
+    c = np.stack([(idx // n ** (n_vars - 1 - d)) % n for d in range(n_vars)], 1).astype(np.float64)
+    norm = np.sqrt((c * c).sum(1))
+    norm[0] = 1.0
+    return (1.0 / norm).astype(np.float32)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class ScgContext:
+    def __init__(self, n_envs: int, n_options: int, pmap: PinballMap, *, device: int = 0, seed: int = 0,
+                 env_id_base: int = 0, gamma: float = 0.99, alpha: float = 1e-3, epsilon: float = 0.05,
+                 r_option_success: float = 100.0, max_episode_steps: int = 10000,
+                 max_option_steps: int = 250):
+        if not torch.cuda.is_available():
+            raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")
+        if not (0 <= n_options <= MAX_OPTIONS):
+            raise ScgError(f"n_options must be in [0, {MAX_OPTIONS}]")
+        self.lib = _lib.load()
+        self.n_envs, self.n_options, self.n_vf = int(n_envs), int(n_options), int(n_options) + 1
+        self.device = torch.device("cuda", device)
+        self.map = pmap
+        self.cfg = ScgConfig(n_envs=n_envs, n_options=n_options, fourier_order=_lib.FOURIER_ORDER,
+                             device=device, env_id_base=env_id_base, seed=seed, gamma=gamma, alpha=alpha,
+                             epsilon=epsilon, r_option_success=r_option_success,
+                             max_episode_steps=max_episode_steps, max_option_steps=max_option_steps)
+        self._ctx = C.c_void_p()
+        _lib.check(self.lib.scg_create(C.byref(self._ctx), C.byref(self.cfg)), None, "scg_create")
+        self.scale = fourier_scale_table()
+        edges, starts, sc = pmap.edges, np.ascontiguousarray(pmap.starts, np.float32), pmap.scalars
+        self._call("scg_set_map", edges.ctypes.data_as(C.c_void_p), len(edges),
+                   starts.ctypes.data_as(C.c_void_p), len(starts), sc.ctypes.data_as(C.c_void_p),
+                   self.scale.ctypes.data_as(C.c_void_p))
+
+    # ------------------------------------------------------------------ plumbing
+    def _call(self, name: str, *args) -> None:
+        _lib.check(getattr(self.lib, name)(self._ctx, *args), self._ctx, name)
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t: torch.Tensor, dtype: torch.dtype, numel: int, name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor) or t.dtype != dtype or t.device != self.device \
+                or not t.is_contiguous() or t.numel() != numel:
+            raise ScgError(f"{name}: expected contiguous {dtype} tensor with {numel} elements on {self.device}, "
+                           f"got {getattr(t, 'dtype', type(t))} {tuple(getattr(t, 'shape', ()))} "
+                           f"on {getattr(t, 'device', '?')}")
+        return t
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.scg_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_hparams(self, **kw) -> None:
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise ScgError(f"unknown hyper-parameter {k}")
+            setattr(self.cfg, k, v)
+        c = self.cfg
+        self._call("scg_set_hparams", c.gamma, c.alpha, c.epsilon, c.r_option_success,
+                   c.max_episode_steps, c.max_option_steps)
+
+    # ------------------------------------------------------------------ fused step-batch
+    def step(self, st: "EnvState", W: torch.Tensor, clf: torch.Tensor, enabled_mask: int, t: int,
+             learn: bool = True, apply: bool = True) -> None:
+        N = self.n_envs
+        f32, i32, u8 = torch.float32, torch.int32, torch.uint8
+        self._chk(st.x, f32, N, "x"); self._chk(st.y, f32, N, "y")
+        self._chk(st.vx, f32, N, "vx"); self._chk(st.vy, f32, N, "vy")
+        self._chk(st.option_id, i32, N, "option_id"); self._chk(st.opt_steps, i32, N, "opt_steps")
+        self._chk(st.ep_steps, i32, N, "ep_steps"); self._chk(st.qcache, f32, NUM_ACTIONS * N, "qcache")
+        self._chk(st.action, u8, N, "action"); self._chk(st.reward, f32, N, "reward")
+        self._chk(st.done, u8, N, "done")
+        self._chk(W, f32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
+        self._chk(clf, f32, self.n_vf * CLF_STRIDE, "clf")
+        flags = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
+        self._call("scg_step", _ptr(st.x), _ptr(st.y), _ptr(st.vx), _ptr(st.vy), _ptr(st.option_id),
+                   _ptr(st.opt_steps), _ptr(st.ep_steps), _ptr(st.qcache), _ptr(st.action), _ptr(st.reward),
+                   _ptr(st.done), _ptr(W), _ptr(clf), C.c_uint32(enabled_mask), C.c_uint64(t),
+                   C.c_uint32(flags), self._stream())
+
+    def grad_buffers(self):
+        """(G[n_vf,5,1296] float32, n_k[n_vf] int32): caller-owned torch tensors that scg_step(LEARN)
+        fills with the rank-local gradient sum and update counts (the all-reduce operands, SPEC §5)."""
+        if not hasattr(self, "_gbuf"):
+            G = torch.zeros((self.n_vf, NUM_ACTIONS, NUM_FEATURES), dtype=torch.float32, device=self.device)
+            n = torch.zeros((self.n_vf,), dtype=torch.int32, device=self.device)
+            self._call("scg_set_grad_buffers", _ptr(G), _ptr(n))
+            self._gbuf = (G, n)
+        return self._gbuf
+
+    def apply_update(self, W: torch.Tensor, G: torch.Tensor, n_k: torch.Tensor) -> None:
+        self._chk(W, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
+        self._chk(G, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "G")
+        self._chk(n_k, torch.int32, self.n_vf, "n_k")
+        self._call("scg_apply_update", _ptr(W), _ptr(G), _ptr(n_k), self._stream())
+
+    # ------------------------------------------------------------------ un-fused entry points
+    def _chk4(self, s: Sequence[torch.Tensor], n: int, name: str):
+        if len(s) != 4:
+            raise ScgError(f"{name}: need (x, y, vx, vy)")
+        return [self._chk(t, torch.float32, n, f"{name}[{i}]") for i, t in enumerate(s)]
+
+    def pinball_step(self, s, action: torch.Tensor):
+        n = s[0].numel()
+        x, y, vx, vy = self._chk4(s, n, "state")
+        self._chk(action, torch.uint8, n, "action")
+        if n and int(action.max()) >= NUM_ACTIONS:
+            raise ScgError("action out of range [0, 5)")
+        reward = torch.empty(n, dtype=torch.float32, device=self.device)
+        goal = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._call("scg_pinball_step", n, _ptr(x), _ptr(y), _ptr(vx), _ptr(vy), _ptr(action), _ptr(reward),
+                   _ptr(goal), self._stream())
+        return reward, goal
+
+    def features(self, s) -> torch.Tensor:
+        n = s[0].numel()
+        x, y, vx, vy = self._chk4(s, n, "state")
+        phi = torch.empty((n, NUM_FEATURES), dtype=torch.float32, device=self.device)
+        self._call("scg_fourier_features", n, _ptr(x), _ptr(y), _ptr(vx), _ptr(vy), _ptr(phi), self._stream())
+        return phi
+
+    def q_values(self, s, Wk: torch.Tensor) -> torch.Tensor:
+        n = s[0].numel()
+        x, y, vx, vy = self._chk4(s, n, "state")
+        self._chk(Wk, torch.float32, NUM_ACTIONS * NUM_FEATURES, "Wk")
+        q = torch.empty((NUM_ACTIONS, n), dtype=torch.float32, device=self.device)
+        self._call("scg_q_values", n, _ptr(x), _ptr(y), _ptr(vx), _ptr(vy), _ptr(Wk), _ptr(q), self._stream())
+        return q
+
+    def q_update(self, k: int, s, action, r, cont, sn, W: torch.Tensor, apply: bool = True) -> None:
+        n = s[0].numel()
+        if n > self.n_envs:
+            raise ScgError("q_update: more transitions than the context's n_envs")
+        x, y, vx, vy = self._chk4(s, n, "s")
+        xn, yn, vxn, vyn = self._chk4(sn, n, "s_next")
+        self._chk(action, torch.uint8, n, "action"); self._chk(r, torch.float32, n, "r")
+        self._chk(cont, torch.float32, n, "cont")
+        self._chk(W, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
+        if n and int(action.max()) >= NUM_ACTIONS:
+            raise ScgError("action out of range [0, 5)")
+        self._call("scg_q_update", n, k, _ptr(x), _ptr(y), _ptr(vx), _ptr(vy), _ptr(action), _ptr(r), _ptr(cont),
+                   _ptr(xn), _ptr(yn), _ptr(vxn), _ptr(vyn), _ptr(W), C.c_uint32(STEP_APPLY if apply else 0),
+                   self._stream())
+
+    def classifier_predict(self, x: torch.Tensor, y: torch.Tensor, w8: torch.Tensor) -> torch.Tensor:
+        n = x.numel()
+        self._chk(x, torch.float32, n, "x"); self._chk(y, torch.float32, n, "y")
+        self._chk(w8, torch.float32, CLF_STRIDE, "w8")
+        out = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._call("scg_classifier_predict", n, _ptr(x), _ptr(y), _ptr(w8), _ptr(out), self._stream())
+        return out
+
+    def fit_initiation(self, xy: torch.Tensor, label: torch.Tensor, offsets: torch.Tensor, w: torch.Tensor,
+                       iters: int = 200, lr: float = 1.0, l2: float = 1e-4) -> None:
+        n_fit = offsets.numel() - 1
+        self._chk(offsets, torch.int32, n_fit + 1, "offsets")
+        off = offsets.cpu()
+        m = int(off[-1])
+        if n_fit < 0 or int(off[0]) != 0 or bool((off[1:] < off[:-1]).any()):
+            raise ScgError("offsets must start at 0 and be non-decreasing")
+        self._chk(xy, torch.float32, 2 * m, "xy"); self._chk(label, torch.uint8, m, "label")
+        self._chk(w, torch.float32, n_fit * CLF_STRIDE, "w")
+        self._call("scg_fit_initiation", n_fit, _ptr(xy), _ptr(label), _ptr(offsets), _ptr(w), iters,
+                   C.c_float(lr), C.c_float(l2), self._stream())
+
+
+class EnvState:
+    """SoA env batch in HBM (caller-owned torch tensors)."""
+
+    def __init__(self, n: int, device: torch.device, pmap: PinballMap):
+        z = lambda dt: torch.zeros(n, dtype=dt, device=device)
+        sx, sy = float(pmap.starts[0][0]), float(pmap.starts[0][1])
+        self.n = n
+        self.x = torch.full((n,), sx, dtype=torch.float32, device=device)
+        self.y = torch.full((n,), sy, dtype=torch.float32, device=device)
+        self.vx, self.vy = z(torch.float32), z(torch.float32)
+        self.option_id, self.opt_steps, self.ep_steps = z(torch.int32), z(torch.int32), z(torch.int32)
+        self.qcache = torch.zeros((NUM_ACTIONS, n), dtype=torch.float32, device=device)
+        self.action, self.done = z(torch.uint8), z(torch.uint8)
+        self.reward = z(torch.float32)
+
+    def state(self):
+        return (self.x, self.y, self.vx, self.vy)

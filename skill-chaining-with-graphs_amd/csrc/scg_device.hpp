@@ -1,0 +1,213 @@
+// scg_device.hpp — gfx950 device primitives for the skill-chaining hot path.
+// Every function implements the SPEC.md section it names, operation for operation (binary32,
+// fusion only where fmaf() is written; the translation unit is built with -ffp-contract=off).
+// There is no upstream code to cite: /root/reference is README.md:1-2 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scg {
+
+constexpr int NACT = 5;
+constexpr int NF = 1296;
+constexpr int NSLOT = 21;          // feature slots per lane (SPEC §3.1)
+constexpr int BLOCK_ENVS = 256;    // SPEC §5 geometry
+constexpr int WAVES = 8;
+constexpr int THREADS = WAVES * 64;
+constexpr int MAX_EDGES = 256;
+constexpr int CLF_STRIDE = 8;
+constexpr int MAX_VF = 6;
+
+// ------------------------------------------------------------------ SPEC §2
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ------------------------------------------------------------------ SPEC §3
+__device__ __forceinline__ float2 sincospi_cs(float t) {   // returns (cos, sin)
+    const float S0 = 0x1.921fb6p+1f, S1 = -0x1.4abbcep+2f, S2 = 0x1.466bc6p+1f, S3 = -0x1.32d2ccp-1f,
+                S4 = 0x1.507834p-4f;
+    const float C0 = -0x1.3bd3ccp+2f, C1 = 0x1.03c1f0p+2f, C2 = -0x1.55d3c8p+0f, C3 = 0x1.e1f506p-3f,
+                C4 = -0x1.a6d1f2p-6f;
+    const float n = rintf(t + t);
+    const float r = fmaf(n, -0.5f, t);
+    const float z = r * r;
+    float sp = fmaf(z, S4, S3); sp = fmaf(z, sp, S2); sp = fmaf(z, sp, S1); sp = fmaf(z, sp, S0); sp = sp * r;
+    float cp = fmaf(z, C4, C3); cp = fmaf(z, cp, C2); cp = fmaf(z, cp, C1); cp = fmaf(z, cp, C0);
+    cp = fmaf(z, cp, 1.0f);
+    const int q = (int)n & 3;
+    float c = cp, s = sp;
+    if (q == 1) { c = -sp; s = cp; }
+    else if (q == 2) { c = -cp; s = -sp; }
+    else if (q == 3) { c = sp; s = -cp; }
+    return make_float2(c, s);
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(-a.y, b.y, a.x * b.x), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// powers Z^1..Z^5 of the four normalised state variables -> dst[d*5 + (k-1)]
+__device__ __forceinline__ void state_powers(float x, float y, float vx, float vy, float2 *dst) {
+    const float sh[4] = {x, y, fmaf(vx, 0.25f, 0.5f), fmaf(vy, 0.25f, 0.5f)};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float2 z1 = sincospi_cs(sh[d]);
+        float2 z = z1;
+        dst[d * 5] = z;
+#pragma unroll
+        for (int k = 2; k <= 5; ++k) { z = cmul(z, z1); dst[d * 5 + k - 1] = z; }
+    }
+}
+
+__device__ __forceinline__ float2 pow_at(const float2 *pw, int d, int k) {   // Z_d^k, k in 0..5
+    const float2 v = pw[d * 5 + (k > 0 ? k - 1 : 0)];
+    return k == 0 ? make_float2(1.0f, 0.0f) : v;
+}
+
+// ------------------------------------------------------------------ SPEC §3.1 butterfly
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ SPEC §1.3
+struct MapScalars {
+    float hstep, R2, TX, TY, TR2, reach2;
+    int n_edges, n_starts;
+};
+
+__device__ __forceinline__ bool intercept(const float4 ea, const float inv_len2, float R2, float x,
+                                          float y, float vx, float vy) {
+    const float KAPPA2 = 0x1.0553bep-14f;
+    const float dx = x - ea.x, dy = y - ea.y;
+    float t = fmaf(dy, ea.w, dx * ea.z) * inv_len2;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float cx = fmaf(ea.z, t, ea.x), cy = fmaf(ea.w, t, ea.y);
+    const float bx = cx - x, by = cy - y;
+    const float d2 = fmaf(by, by, bx * bx);
+    if (d2 > R2) return false;
+    const float dot = fmaf(by, vy, bx * vx);
+    if (dot >= 0.0f) return true;
+    const float vv = fmaf(vy, vy, vx * vx);
+    return dot * dot <= (KAPPA2 * d2) * vv;
+}
+
+// squared distance from (x,y) to edge (prefilter only; same formula as intercept's d2)
+__device__ __forceinline__ float edge_d2(const float4 ea, const float inv_len2, float x, float y) {
+    const float dx = x - ea.x, dy = y - ea.y;
+    float t = fmaf(dy, ea.w, dx * ea.z) * inv_len2;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float cx = fmaf(ea.z, t, ea.x), cy = fmaf(ea.w, t, ea.y);
+    const float bx = cx - x, by = cy - y;
+    return fmaf(by, by, bx * bx);
+}
+
+// One env step. `edges` = LDS table [n_edges][8]. Returns reward; goal flag by reference.
+__device__ __forceinline__ float pinball_step(const float *edges, const MapScalars &ms, float &x, float &y,
+                                              float &vx, float &vy, int a, bool &goal_out) {
+    const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
+    const float4 *E4 = reinterpret_cast<const float4 *>(edges);
+    // conservative candidate set: edges within 4.25 R of the start position (SPEC §1.3, last paragraph)
+    uint64_t cand[MAX_EDGES / 64];
+#pragma unroll
+    for (int g = 0; g < MAX_EDGES / 64; ++g) {
+        uint64_t m = 0;
+        if (g * 64 < ms.n_edges) {
+            const int jn = min(64, ms.n_edges - g * 64);
+            for (int j = 0; j < jn; ++j) {
+                const float4 ea = E4[2 * (g * 64 + j)];
+                const float inv = edges[8 * (g * 64 + j) + 4];
+                if (edge_d2(ea, inv, x, y) <= ms.reach2) m |= (1ull << j);
+            }
+        }
+        cand[g] = m;
+    }
+    if (a == 0) vx = vx + DV;
+    else if (a == 2) vx = vx - DV;
+    else if (a == 1) vy = vy + DV;
+    else if (a == 3) vy = vy - DV;
+    vx = fminf(fmaxf(vx, -VMAX), VMAX);
+    vy = fminf(fmaxf(vy, -VMAX), VMAX);
+    bool goal = false;
+    const float h = ms.hstep;
+    for (int i = 0; i < 20; ++i) {
+        x = fmaf(vx, h, x); y = fmaf(vy, h, y);
+        int nhit = 0, first = -1;
+#pragma unroll
+        for (int g = 0; g < MAX_EDGES / 64; ++g) {
+            uint64_t m = cand[g];
+            while (m) {
+                const int j = g * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 ea = E4[2 * j];
+                const float inv = edges[8 * j + 4];
+                if (intercept(ea, inv, ms.R2, x, y, vx, vy)) {
+                    if (nhit == 0) first = j;
+                    ++nhit;
+                }
+            }
+        }
+        if (nhit == 1) {
+            const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
+            const float pr = fmaf(vy, uy, vx * ux);
+            const float tp = pr + pr;
+            const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
+            vx = nvx; vy = nvy;
+            if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
+        } else if (nhit > 1) {
+            vx = -vx; vy = -vy;
+        }
+        const float gx = x - ms.TX, gy = y - ms.TY;
+        if (fmaf(gy, gy, gx * gx) < ms.TR2) { goal = true; break; }
+    }
+    float reward;
+    if (goal) {
+        reward = 10000.0f;
+    } else {
+        vx = vx * DRAG; vy = vy * DRAG;
+        x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f);
+        reward = (a == 4) ? -1.0f : -5.0f;
+    }
+    goal_out = goal;
+    return reward;
+}
+
+// ------------------------------------------------------------------ SPEC §4.1
+__device__ __forceinline__ float clf_z(const float *w, float x, float y) {
+    const float u = fmaf(x, 2.0f, -1.0f), v = fmaf(y, 2.0f, -1.0f);
+    float z = w[0];
+    z = fmaf(w[1], u, z); z = fmaf(w[2], v, z);
+    z = fmaf(w[3], u * u, z); z = fmaf(w[4], u * v, z); z = fmaf(w[5], v * v, z);
+    return z;
+}
+
+// ------------------------------------------------------------------ SPEC §6
+__device__ __forceinline__ float sigmoid_spec(float z) {
+    const float LOG2E = 0x1.715476p+0f, LN2HI = 0x1.63p-1f, LN2LO = -0x1.bd0106p-13f;
+    const float E2 = 0x1p-1f, E3 = 0x1.555556p-3f, E4 = 0x1.555556p-5f, E5 = 0x1.111112p-7f,
+                E6 = 0x1.6c16c2p-10f, E7 = 0x1.a01a02p-13f;
+    float a = -fabsf(z);
+    a = fmaxf(a, -87.0f);
+    const float n = rintf(a * LOG2E);
+    float r = fmaf(n, -LN2HI, a);
+    r = fmaf(n, -LN2LO, r);
+    float p = E7;
+    p = fmaf(p, r, E6); p = fmaf(p, r, E5); p = fmaf(p, r, E4); p = fmaf(p, r, E3);
+    p = fmaf(p, r, E2); p = fmaf(p, r, 1.0f); p = fmaf(p, r, 1.0f);
+    const float sc = __uint_as_float((uint32_t)((int)n + 127) << 23);
+    const float e = p * sc;
+    return z >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+}
+
+}  // namespace scg

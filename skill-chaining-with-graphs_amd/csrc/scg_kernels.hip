@@ -1,0 +1,868 @@
+// scg_kernels.hip — gfx950 kernels + the C-ABI of include/scg_abi.h.
+//
+// Layout of one step-batch (SPEC §5): a workgroup = 8 wavefronts owns 256 consecutive envs.
+//   phase P  (one lane per env)      act from qcache, Pinball physics with the edge table in LDS,
+//                                    reset/bookkeeping, option termination + selection
+//   phase Z  (one lane per env-state) unit-complex powers Z_d^k of s and s_next -> LDS
+//   phase TD (one lane per 21 features, one item per wave at a time), VF by VF:
+//            W_k and the gradient accumulator live in registers (2 x 105 VGPRs);
+//            Q(s_next,.) / Q(s,a) by fma chains + a 64-lane butterfly; per-wave accumulators are
+//            summed in wave order through LDS and stored as the block's partial slab
+//   reduce   slabs -> G (block order), n_k, W += alpha/n_k * scale * G
+// No upstream code exists to cite (reference = README.md:1-2); sections cite SPEC.md.
+#include "scg_device.hpp"
+#include "../../include/scg_abi.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace scg;
+
+// ------------------------------------------------------------------------------------------------
+// LDS map of the step kernel (bytes)
+constexpr int OFF_EDGES = 0;                                   // float[256][8]
+constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][256], sn[4][256]
+constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [256]
+constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [256] (+pad)
+constexpr int OFF_POW = OFF_INT + 4 * BLOCK_ENVS;              // float2 pow[256][2][20]
+constexpr int OFF_AB = OFF_POW + BLOCK_ENVS * 2 * 20 * 8;      // float2 ab[8][2][36]
+constexpr int OFF_BUF = OFF_AB + WAVES * 2 * 36 * 8;           // float buf[5*1296]
+constexpr int OFF_LIST = OFF_BUF + NACT * NF * 4;              // uint16 list[256]
+constexpr int OFF_MISC = OFF_LIST + BLOCK_ENVS * 2;            // int misc[16]
+constexpr int LDS_BYTES = OFF_MISC + 64;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(OFF_POW % 16 == 0 && OFF_AB % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
+
+enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
+
+struct StepArgs {
+    // env state (FUSED: in/out; TRANS/QVAL: in)
+    float *x, *y, *vx, *vy;
+    int32_t *option_id, *opt_steps, *ep_steps;
+    float *qcache;                 // [5][n]  (QVAL: output q)
+    uint8_t *action;               // FUSED: out; TRANS: in
+    float *reward;                 // FUSED: out; TRANS: in (r)
+    uint8_t *done;
+    const float *cont_in;          // TRANS
+    const float *xn, *yn, *vxn, *vyn;   // TRANS
+    const float *W;                // [n_vf][5][1296] (QVAL: one VF)
+    const float *clf;              // [n_vf][8]
+    const float *edges;            // device [n_edges][8]
+    const float *starts;           // device [n_starts][2]
+    float *slabs;                  // [nblk][n_vf][5][1296]
+    int32_t *cnts;                 // [nblk][n_vf]
+    int32_t n, n_vf, k_lo, k_hi;
+    uint32_t enabled, learn;
+    uint64_t t, seed;
+    int64_t env_base;
+    float gamma, epsilon, r_succ;
+    int32_t max_ep, max_opt;
+    MapScalars ms;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ bool in_set(const StepArgs &A, int k, float x, float y) {
+    if (k < 1 || k >= A.n_vf) return false;
+    if (!((A.enabled >> k) & 1u)) return false;
+    return clf_z(A.clf + CLF_STRIDE * k, x, y) > 0.0f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_edges = reinterpret_cast<float *>(smem + OFF_EDGES);
+    float *s_s = reinterpret_cast<float *>(smem + OFF_S);              // [8][256]: s then sn
+    float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
+    float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
+    uint8_t *s_a = reinterpret_cast<uint8_t *>(smem + OFF_INT);
+    uint8_t *s_ot = s_a + BLOCK_ENVS, *s_on = s_ot + BLOCK_ENVS;
+    float2 *s_pow = reinterpret_cast<float2 *>(smem + OFF_POW);
+    float2 *s_ab = reinterpret_cast<float2 *>(smem + OFF_AB);
+    float *s_buf = reinterpret_cast<float *>(smem + OFF_BUF);
+    uint16_t *s_list = reinterpret_cast<uint16_t *>(smem + OFF_LIST);
+    int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int e0 = b * BLOCK_ENVS;
+    const int nb = min(BLOCK_ENVS, A.n - e0);
+    const int N = A.n;
+
+    if (MODE == MODE_FUSED) {
+        for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ phase P
+    if (tid < BLOCK_ENVS) {
+        const int i = tid, e = e0 + i;
+        if (i < nb) {
+            if (MODE == MODE_FUSED) {
+                // act (SPEC §2, §4.3)
+                const uint64_t g = (uint64_t)(A.env_base + e);
+                uint32_t u[4];
+                philox4x32_10((uint32_t)g, (uint32_t)(A.t & 0xffffffffu), (uint32_t)(A.t >> 32), 0u,
+                              (uint32_t)(A.seed & 0xffffffffu), (uint32_t)(A.seed >> 32), u);
+                const bool explore = (float)(u[0] >> 8) * 0x1p-24f < A.epsilon;
+                const int a_rand = (int)__umulhi(u[1], 5u);
+                int a_greedy = 0;
+                float best = A.qcache[e];
+#pragma unroll
+                for (int a = 1; a < NACT; ++a) {
+                    const float q = A.qcache[(size_t)a * N + e];
+                    if (q > best) { best = q; a_greedy = a; }
+                }
+                const int a = explore ? a_rand : a_greedy;
+                float sx = A.x[e], sy = A.y[e], svx = A.vx[e], svy = A.vy[e];
+                s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
+                s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
+                // physics (SPEC §1.3)
+                bool goal;
+                const float rew = pinball_step(s_edges, A.ms, sx, sy, svx, svy, a, goal);
+                // bookkeeping (SPEC §1.4)
+                const int eps1 = A.ep_steps[e] + 1;
+                const bool timeout = !goal && eps1 >= A.max_ep;
+                const int dn = goal ? 1 : (timeout ? 2 : 0);
+                float nx = sx, ny = sy, nvx = svx, nvy = svy;
+                if (dn) {
+                    const uint32_t si = __umulhi(u[2], (uint32_t)A.ms.n_starts);
+                    nx = A.starts[2 * si]; ny = A.starts[2 * si + 1]; nvx = 0.0f; nvy = 0.0f;
+                }
+                s_s[4 * BLOCK_ENVS + i] = nx; s_s[5 * BLOCK_ENVS + i] = ny;
+                s_s[6 * BLOCK_ENVS + i] = nvx; s_s[7 * BLOCK_ENVS + i] = nvy;
+                // options (SPEC §4.2)
+                const int o = A.option_id[e];
+                const int osteps = A.opt_steps[e];
+                bool keep = false;
+                float ro = 0.0f, co = 0.0f;
+                if (o >= 1) {
+                    const bool succ = (o == 1) ? goal : in_set(A, o - 1, sx, sy);
+                    const bool fail = !succ && !in_set(A, o, sx, sy);
+                    const bool otime = osteps + 1 >= A.max_opt;
+                    const bool term = (dn != 0) || succ || fail || otime;
+                    ro = rew + (succ ? A.r_succ : 0.0f);
+                    co = term ? 0.0f : A.gamma;
+                    keep = !term;
+                }
+                int on = 0;
+                if (keep) on = o;
+                else {
+                    for (int k = 1; k < A.n_vf; ++k) {
+                        if (!in_set(A, k, nx, ny)) continue;
+                        if (k >= 2 && in_set(A, k - 1, nx, ny)) continue;
+                        on = k;
+                        break;
+                    }
+                }
+                s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
+                s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
+                A.action[e] = (uint8_t)a; A.reward[e] = rew; A.done[e] = (uint8_t)dn;
+                A.x[e] = nx; A.y[e] = ny; A.vx[e] = nvx; A.vy[e] = nvy;
+                A.option_id[e] = on;
+                A.opt_steps[e] = keep ? osteps + 1 : 0;
+                A.ep_steps[e] = dn ? 0 : eps1;
+            } else if (MODE == MODE_TRANS) {
+                s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
+                s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
+                s_s[4 * BLOCK_ENVS + i] = A.xn[e]; s_s[5 * BLOCK_ENVS + i] = A.yn[e];
+                s_s[6 * BLOCK_ENVS + i] = A.vxn[e]; s_s[7 * BLOCK_ENVS + i] = A.vyn[e];
+                s_a[i] = A.action[e]; s_ot[i] = (uint8_t)A.k_lo; s_on[i] = 255;
+                const float r = A.reward[e], c = A.cont_in[e];
+                s_r0[i] = r; s_c0[i] = c; s_ro[i] = r; s_co[i] = c;
+            } else {
+                s_s[4 * BLOCK_ENVS + i] = A.x[e]; s_s[5 * BLOCK_ENVS + i] = A.y[e];
+                s_s[6 * BLOCK_ENVS + i] = A.vx[e]; s_s[7 * BLOCK_ENVS + i] = A.vy[e];
+                s_a[i] = 0; s_ot[i] = 255; s_on[i] = (uint8_t)A.k_lo;
+                s_r0[i] = 0.0f; s_c0[i] = 0.0f; s_ro[i] = 0.0f; s_co[i] = 0.0f;
+            }
+        } else {
+            s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ phase Z (SPEC §3)
+    {
+        const int i = tid & (BLOCK_ENVS - 1), sg = tid >> 8;
+        if (i < nb && (MODE != MODE_QVAL || sg == 1)) {
+            const float *st = s_s + sg * 4 * BLOCK_ENVS;
+            state_powers(st[i], st[BLOCK_ENVS + i], st[2 * BLOCK_ENVS + i], st[3 * BLOCK_ENVS + i],
+                         s_pow + (i * 2 + sg) * 20);
+        }
+    }
+
+    // lane-constant feature coordinates (SPEC §3.1)
+    const int hi = lane >> 5, col = lane & 31;
+    const int c3m = col / 6, c4m = col - 6 * c3m;        // main column c34 = col
+    const int c4t = 2 + (lane & 3);                       // tail column c34 = 32 + (lane&3): c3 = 5
+    const int c1p = lane / 6, c2p = lane - 6 * c1p;       // AB product owned by lanes 0..35
+    const int tl = lane >> 2;                             // tail row part: c12 = 16 t + tl
+    const bool v20 = lane < 16;                           // slot 20 holds a feature only in lanes 0..15
+
+    // Per-lane base pointers; every access below is base[compile-time constant], so the address is one
+    // VGPR + an immediate (hipcc otherwise materialises ~100 separate addresses and spills them).
+    float2 *abw = s_ab + wave * 72;                       // [0..35] = AB(s), [36..71] = AB(s_next)
+    const float2 *ab_m = abw + hi;                        // main slots:  ab_m[36*sigma + 2j]
+    const float2 *ab_t = abw + tl;                        // tail slots 18,19: ab_t[36*sigma + 16t]
+    const float2 *ab_t2 = abw + min(32 + tl, 35);         // tail slot 20 (clamped; masked by v20)
+    float *buf_m = s_buf + hi * 36 + col;                 // buf_m[a*NF + 72j]
+    float *buf_t = s_buf + tl * 36 + 32 + (lane & 3);     // buf_t[a*NF + 576t]
+    const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets, same split
+    const uint32_t w_vt = (uint32_t)(tl * 36 + 32 + (lane & 3)) * 4u;
+
+    float Wr[NACT][NSLOT], dW[NACT][NSLOT];
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A.W), 0, (MODE == MODE_QVAL ? 1 : A.n_vf) * NACT * NF * 4, 0x00020000);
+
+// phi of slot J for state SG (0 = s, 1 = s_next) given that state's column factors cdm / cdt
+#define SCG_PHI(J, SG, PH)                                                                   \
+    float PH;                                                                                \
+    {                                                                                        \
+        const float2 ab_ = (J) < 18 ? ab_m[36 * (SG) + 2 * (J)]                              \
+                                    : ((J) < 20 ? ab_t[36 * (SG) + 16 * ((J)-18)] : ab_t2[36 * (SG)]); \
+        const float2 cd_ = (J) < 18 ? cdm : cdt;                                             \
+        PH = fmaf(-ab_.y, cd_.y, ab_.x * cd_.x);                                             \
+        if ((J) == 20) PH = v20 ? PH : 0.0f;                                                 \
+    }
+
+    // ------------------------------------------------------------------ phase TD, VF by VF (SPEC §5)
+    for (int k = A.k_lo; k <= A.k_hi; ++k) {
+        __syncthreads();
+        bool has = false, upd = false;
+        if (tid < nb) {
+            const int ot = s_ot[tid], on = s_on[tid];
+            upd = (MODE != MODE_QVAL) && A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
+            has = upd || (on == k);
+        }
+        uint64_t mh = 0;
+        if (wave < 4) {
+            mh = __ballot(has);
+            const uint64_t mu = __ballot(upd);
+            if (lane == 0) { s_misc[wave] = __popcll(mh); s_misc[4 + wave] = __popcll(mu); }
+        }
+        __syncthreads();
+        if (wave < 4 && has) {
+            int off = 0;
+            for (int w2 = 0; w2 < wave; ++w2) off += s_misc[w2];
+            s_list[off + __popcll(mh & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+        }
+        const int m = s_misc[0] + s_misc[1] + s_misc[2] + s_misc[3];
+        const int nupd = s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
+        __syncthreads();
+        if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = nupd;
+        if (m == 0) continue;
+
+        // W_k -> registers: one descriptor, lane offset in a VGPR, everything else in the scalar offset
+        {
+            const uint32_t kbase = (MODE == MODE_QVAL) ? 0u : (uint32_t)k * (NACT * NF * 4);
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+                for (int j = 0; j < 18; ++j)
+                    Wr[a][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        w_rsrc, w_vm, kbase + (uint32_t)(a * NF + 72 * j) * 4u, 0));
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        w_rsrc, (t < 2 || v20) ? w_vt : 0u, kbase + (uint32_t)(a * NF + 576 * t) * 4u, 0));
+                    Wr[a][18 + t] = (t < 2 || v20) ? v : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) dW[a][j] = 0.0f;
+            }
+        }
+
+        for (int it = wave; it < m; it += WAVES) {
+            const int i = __builtin_amdgcn_readfirstlane((int)s_list[it]);
+            const int ot = s_ot[i], on = s_on[i];
+            const bool u = (MODE != MODE_QVAL) && A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
+            const bool cache = (on == k);
+            const float r = (k == 0) ? s_r0[i] : s_ro[i];
+            const float cont = (k == 0) ? s_c0[i] : s_co[i];
+            const bool tgt = u && cont > 0.0f;
+            const bool ev = tgt || cache;
+            const float2 *pw_s = s_pow + (i * 2 + 0) * 20;
+            const float2 *pw_n = s_pow + (i * 2 + 1) * 20;
+            if (lane < 36) {
+                if (ev) abw[36 + lane] = cmul(pow_at(pw_n, 0, c1p), pow_at(pw_n, 1, c2p));
+                if (u) abw[lane] = cmul(pow_at(pw_s, 0, c1p), pow_at(pw_s, 1, c2p));
+            }
+            wave_lds_sync();
+            float q[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (ev) {
+                const float2 cdm = cmul(pow_at(pw_n, 2, c3m), pow_at(pw_n, 3, c4m));
+                const float2 cdt = cmul(pow_at(pw_n, 2, 5), pow_at(pw_n, 3, c4t));
+#pragma unroll
+                for (int j = 0; j < NSLOT; ++j) {
+                    SCG_PHI(j, 1, ph)
+#pragma unroll
+                    for (int a = 0; a < NACT; ++a) q[a] = fmaf(Wr[a][j], ph, q[a]);
+                }
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) q[a] = wave_sum(q[a]);
+                if (cache && lane < NACT) {
+                    const float v = lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : lane == 3 ? q[3] : q[4];
+                    A.qcache[(size_t)lane * N + e0 + i] = v;
+                }
+            }
+            if (u) {
+                const int at = s_a[i];
+                const float2 cdm = cmul(pow_at(pw_s, 2, c3m), pow_at(pw_s, 3, c4m));
+                const float2 cdt = cmul(pow_at(pw_s, 2, 5), pow_at(pw_s, 3, c4t));
+                // phi(s) is evaluated twice (for Q(s,a), then for the accumulate) instead of being held in
+                // 21 VGPRs across the butterfly: W + dW already take 210 of the 256 registers.
+                float qsa = 0.0f;
+#define SCG_QSA_CASE(AA)                                                   \
+    case AA:                                                               \
+        _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
+            SCG_PHI(j, 0, ph)                                              \
+            qsa = fmaf(Wr[AA][j], ph, qsa);                                \
+        }                                                                  \
+        break;
+                switch (at) { SCG_QSA_CASE(0) SCG_QSA_CASE(1) SCG_QSA_CASE(2) SCG_QSA_CASE(3) default:
+                    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
+                        SCG_PHI(j, 0, ph)
+                        qsa = fmaf(Wr[4][j], ph, qsa);
+                    }
+                    break; }
+#undef SCG_QSA_CASE
+                qsa = wave_sum(qsa);
+                float mx = q[0];
+#pragma unroll
+                for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, q[a]);
+                const float target = tgt ? fmaf(cont, mx, r) : r;
+                const float delta = target - qsa;
+#define SCG_UPD_CASE(AA)                                                   \
+    case AA:                                                               \
+        _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
+            SCG_PHI(j, 0, ph)                                              \
+            dW[AA][j] = fmaf(delta, ph, dW[AA][j]);                        \
+        }                                                                  \
+        break;
+                switch (at) { SCG_UPD_CASE(0) SCG_UPD_CASE(1) SCG_UPD_CASE(2) SCG_UPD_CASE(3) default:
+                    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
+                        SCG_PHI(j, 0, ph)
+                        dW[4][j] = fmaf(delta, ph, dW[4][j]);
+                    }
+                    break; }
+#undef SCG_UPD_CASE
+            }
+            wave_lds_sync();
+        }
+
+        if (MODE == MODE_QVAL || nupd == 0) continue;
+        // block partial: ((acc_0 + acc_1) + ...) + acc_7, through LDS in wave order
+        for (int w = 0; w < WAVES; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+                    for (int j = 0; j < 18; ++j) {
+                        float *p = &buf_m[a * NF + 72 * j];
+                        *p = (w == 0) ? dW[a][j] : *p + dW[a][j];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (t < 2 || v20) {
+                            float *p = &buf_t[a * NF + 576 * t];
+                            *p = (w == 0) ? dW[a][18 + t] : *p + dW[a][18 + t];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
+        for (int f = tid; f < NACT * NF; f += THREADS) slab[f] = s_buf[f];
+    }
+#undef SCG_PHI
+}
+
+// ------------------------------------------------------------------------------------------------
+// slabs -> G (block order), n_k; optional apply (SPEC §5)
+struct ReduceArgs {
+    const float *slabs;
+    const int32_t *cnts;
+    float *G;
+    int32_t *n_k;
+    float *W;
+    const float *scale;
+    int32_t nblk, n_vf;
+    float alpha;
+    uint32_t apply;
+};
+
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
+    __shared__ int s_cnt[256];
+    const int k = blockIdx.y;
+    const int tid = threadIdx.x;
+    int c = 0;
+    for (int b = tid; b < R.nblk; b += 256) c += R.cnts[(size_t)b * R.n_vf + k];
+    s_cnt[tid] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) s_cnt[tid] += s_cnt[tid + s];
+        __syncthreads();
+    }
+    const int nk = s_cnt[0];
+    const int i = blockIdx.x * 256 + tid;
+    if (blockIdx.x == 0 && tid == 0) R.n_k[k] = nk;
+    if (i >= NACT * NF) return;
+    float S = 0.0f;
+    const size_t stride = (size_t)R.n_vf * NACT * NF;
+    const float *p = R.slabs + (size_t)k * NACT * NF + i;
+    for (int b = 0; b < R.nblk; ++b) {
+        if (R.cnts[(size_t)b * R.n_vf + k] > 0) S = S + p[(size_t)b * stride];
+    }
+    R.G[(size_t)k * NACT * NF + i] = S;
+    if (R.apply && nk > 0) {
+        const float step = R.alpha / (float)nk;
+        const int f = i % NF;
+        float *w = R.W + (size_t)k * NACT * NF + i;
+        *w = fmaf(step * R.scale[f], S, *w);
+    }
+}
+
+__global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, const int32_t *n_k,
+                                                    const float *scale, float alpha) {
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NACT * NF) return;
+    const int nk = n_k[k];
+    if (nk <= 0) return;
+    const float step = alpha / (float)nk;
+    const int f = i % NF;
+    float *w = W + (size_t)k * NACT * NF + i;
+    *w = fmaf(step * scale[f], G[(size_t)k * NACT * NF + i], *w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// un-fused kernels
+__global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y, float *vx, float *vy,
+                                                      const uint8_t *action, float *reward, uint8_t *goal,
+                                                      const float *edges, MapScalars ms) {
+    __shared__ __attribute__((aligned(16))) float s_edges[MAX_EDGES * 8];
+    for (int i = threadIdx.x; i < ms.n_edges * 8; i += 256) s_edges[i] = edges[i];
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float sx = x[e], sy = y[e], svx = vx[e], svy = vy[e];
+    bool g;
+    const float r = pinball_step(s_edges, ms, sx, sy, svx, svy, action[e], g);
+    x[e] = sx; y[e] = sy; vx[e] = svx; vy[e] = svy;
+    reward[e] = r; goal[e] = g ? 1 : 0;
+}
+
+// one wavefront per env: materialises phi[n][1296] (the fused path never does this)
+__global__ __launch_bounds__(64) void features_kernel(int n, const float *x, const float *y, const float *vx,
+                                                      const float *vy, float *phi) {
+    __shared__ float2 s_pw[20];
+    __shared__ float2 s_abcd[72];
+    const int lane = threadIdx.x;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        if (lane == 0) state_powers(x[e], y[e], vx[e], vy[e], s_pw);
+        wave_lds_sync();
+        for (int p = lane; p < 72; p += 64) {
+            const int q = p % 36, d0 = p < 36 ? 0 : 2;
+            s_abcd[p] = cmul(pow_at(s_pw, d0, q / 6), pow_at(s_pw, d0 + 1, q % 6));
+        }
+        wave_lds_sync();
+        for (int f = lane; f < NF; f += 64) {
+            const float2 ab = s_abcd[f / 36], cd = s_abcd[36 + f % 36];
+            phi[(size_t)e * NF + f] = fmaf(-ab.y, cd.y, ab.x * cd.x);
+        }
+        wave_lds_sync();
+    }
+}
+
+__global__ __launch_bounds__(256) void predict_kernel(int n, const float *x, const float *y, const float *w8,
+                                                      uint8_t *out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = clf_z(w8, x[e], y[e]) > 0.0f ? 1 : 0;
+}
+
+// SPEC §6: one 256-thread workgroup per option
+__global__ __launch_bounds__(256) void fit_kernel(const float *xy, const uint8_t *label, const int32_t *offsets,
+                                                  float *w, int iters, float lr, float l2) {
+    __shared__ float sw[8];
+    __shared__ float swave[4][6];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = offsets[q], M = offsets[q + 1] - offsets[q];
+    if (M <= 0) return;
+    if (tid < 8) sw[tid] = w[CLF_STRIDE * q + tid];
+    const float invM = 1.0f / (float)M;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();
+        float g[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = tid; i < M; i += 256) {
+            const float xx = xy[2 * (size_t)(i0 + i)], yy = xy[2 * (size_t)(i0 + i) + 1];
+            const float u = fmaf(xx, 2.0f, -1.0f), v = fmaf(yy, 2.0f, -1.0f);
+            const float psi[6] = {1.0f, u, v, u * u, u * v, v * v};
+            const float z = clf_z(sw, xx, yy);
+            const float e = sigmoid_spec(z) - (float)label[i0 + i];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) g[j] = fmaf(e, psi[j], g[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            g[j] = wave_sum(g[j]);
+            if (lane == 0) swave[wave][j] = g[j];
+        }
+        __syncthreads();
+        if (tid < 6) {
+            const int j = tid;
+            const float gs = ((swave[0][j] + swave[1][j]) + swave[2][j]) + swave[3][j];
+            const float reg = (j > 0) ? l2 * sw[j] : 0.0f;
+            sw[j] = sw[j] - lr * ((gs * invM) + reg);
+        }
+    }
+    __syncthreads();
+    if (tid < 6) w[CLF_STRIDE * q + tid] = sw[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: the C-ABI
+struct scg_ctx {
+    scg_config cfg;
+    int n_vf;
+    int nblk;
+    bool have_map;
+    MapScalars ms;
+    float *d_edges, *d_starts, *d_scale;
+    float *d_slabs;
+    int32_t *d_cnts;
+    float *d_G;
+    int32_t *d_nk;
+    float *G_out;          // where reduce leaves G / n_k (ctx-owned by default)
+    int32_t *nk_out;
+    bool prof_on;          // measurement hook: event pairs round the fused kernel
+    std::vector<hipEvent_t> *prof_ev;
+    size_t prof_used;
+    char err[256];
+};
+
+static thread_local char g_err[256] = "";
+
+#define SCG_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            snprintf((ctx) ? (ctx)->err : g_err, 256, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            return SCG_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+static int fail(scg_ctx *ctx, int code, const char *msg) {
+    snprintf(ctx ? ctx->err : g_err, 256, "%s", msg);
+    return code;
+}
+
+extern "C" {
+
+int scg_abi_version(void) { return SCG_ABI_VERSION; }
+
+const char *scg_strerror(int status) {
+    switch (status) {
+        case SCG_OK: return "ok";
+        case SCG_ERR_INVALID: return "invalid argument";
+        case SCG_ERR_NO_DEVICE: return "no usable HIP device";
+        case SCG_ERR_HIP: return "HIP runtime error";
+        case SCG_ERR_STATE: return "call order / state error";
+        default: return "unknown status";
+    }
+}
+
+const char *scg_last_error(const scg_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int scg_create(scg_ctx **out, const scg_config *cfg) {
+    if (!out || !cfg) return fail(nullptr, SCG_ERR_INVALID, "scg_create: null argument");
+    *out = nullptr;
+    if (cfg->n_envs < 1) return fail(nullptr, SCG_ERR_INVALID, "scg_create: n_envs must be >= 1");
+    if (cfg->n_options < 0 || cfg->n_options > SCG_MAX_OPTIONS)
+        return fail(nullptr, SCG_ERR_INVALID, "scg_create: n_options out of range [0,5]");
+    if (cfg->fourier_order != SCG_FOURIER_ORDER)
+        return fail(nullptr, SCG_ERR_INVALID, "scg_create: only Fourier order 5 is built");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, SCG_ERR_NO_DEVICE, "scg_create: no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, SCG_ERR_INVALID, "scg_create: device ordinal out of range");
+    scg_ctx *c = new (std::nothrow) scg_ctx();
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_create: out of host memory");
+    memset(c, 0, sizeof(*c));
+    c->cfg = *cfg;
+    c->n_vf = cfg->n_options + 1;
+    c->nblk = (cfg->n_envs + BLOCK_ENVS - 1) / BLOCK_ENVS;
+    int st = SCG_OK;
+    do {
+        if (hipSetDevice(cfg->device) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        const size_t slab_bytes = (size_t)c->nblk * c->n_vf * NACT * NF * sizeof(float);
+        if (hipMalloc(&c->d_slabs, slab_bytes) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_cnts, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_G, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_nk, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_edges, MAX_EDGES * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMemset(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMemset(c->d_G, 0, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMemset(c->d_nk, 0, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&td_kernel<MODE_FUSED>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&td_kernel<MODE_TRANS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&td_kernel<MODE_QVAL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) { st = SCG_ERR_HIP; break; }
+    } while (0);
+    if (st != SCG_OK) {
+        snprintf(g_err, 256, "scg_create: device allocation/setup failed: %s", hipGetErrorString(hipGetLastError()));
+        scg_destroy(c);
+        return st;
+    }
+    c->G_out = c->d_G; c->nk_out = c->d_nk;
+    *out = c;
+    return SCG_OK;
+}
+
+int scg_destroy(scg_ctx *c) {
+    if (!c) return SCG_OK;
+    (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
+    (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale);
+    if (c->prof_ev) {
+        for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
+        delete c->prof_ev;
+    }
+    delete c;
+    return SCG_OK;
+}
+
+int scg_set_hparams(scg_ctx *c, float gamma, float alpha, float epsilon, float r_option_success,
+                    int32_t max_episode_steps, int32_t max_option_steps) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_hparams: null ctx");
+    c->cfg.gamma = gamma; c->cfg.alpha = alpha; c->cfg.epsilon = epsilon;
+    c->cfg.r_option_success = r_option_success;
+    c->cfg.max_episode_steps = max_episode_steps; c->cfg.max_option_steps = max_option_steps;
+    return SCG_OK;
+}
+
+int scg_set_map(scg_ctx *c, const float *edges, int32_t n_edges, const float *starts, int32_t n_starts,
+                const float map_scalars[6], const float *scale) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_map: null ctx");
+    if (!edges || !starts || !map_scalars || !scale) return fail(c, SCG_ERR_INVALID, "scg_set_map: null argument");
+    if (n_edges < 0 || n_edges > MAX_EDGES) return fail(c, SCG_ERR_INVALID, "scg_set_map: n_edges out of range [0,256]");
+    if (n_starts < 1) return fail(c, SCG_ERR_INVALID, "scg_set_map: need at least one start position");
+    SCG_HIP(c, hipSetDevice(c->cfg.device));
+    if (c->d_starts) { (void)hipFree(c->d_starts); c->d_starts = nullptr; }
+    SCG_HIP(c, hipMalloc(&c->d_starts, (size_t)n_starts * 2 * sizeof(float)));
+    if (n_edges > 0) SCG_HIP(c, hipMemcpy(c->d_edges, edges, (size_t)n_edges * 8 * sizeof(float), hipMemcpyHostToDevice));
+    SCG_HIP(c, hipMemcpy(c->d_starts, starts, (size_t)n_starts * 2 * sizeof(float), hipMemcpyHostToDevice));
+    SCG_HIP(c, hipMemcpy(c->d_scale, scale, NF * sizeof(float), hipMemcpyHostToDevice));
+    const float R = map_scalars[0];
+    c->ms.hstep = map_scalars[1]; c->ms.R2 = map_scalars[2];
+    c->ms.TX = map_scalars[3]; c->ms.TY = map_scalars[4]; c->ms.TR2 = map_scalars[5];
+    c->ms.reach2 = (float)((4.25 * (double)R) * (4.25 * (double)R));
+    c->ms.n_edges = n_edges; c->ms.n_starts = n_starts;
+    c->have_map = true;
+    return SCG_OK;
+}
+
+static void fill_common(const scg_ctx *c, StepArgs &A) {
+    memset(&A, 0, sizeof(A));
+    A.n_vf = c->n_vf;
+    A.seed = c->cfg.seed; A.env_base = c->cfg.env_id_base;
+    A.gamma = c->cfg.gamma; A.epsilon = c->cfg.epsilon; A.r_succ = c->cfg.r_option_success;
+    A.max_ep = c->cfg.max_episode_steps; A.max_opt = c->cfg.max_option_steps;
+    A.ms = c->ms;
+    A.edges = c->d_edges; A.starts = c->d_starts;
+    A.slabs = c->d_slabs; A.cnts = c->d_cnts;
+}
+
+static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStream_t s) {
+    ReduceArgs R;
+    R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
+    R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
+    dim3 grid((NACT * NF + 255) / 256, c->n_vf);
+    hipLaunchKernelGGL(reduce_kernel, grid, dim3(256), 0, s, R);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *option_id, int32_t *opt_steps,
+             int32_t *ep_steps, float *qcache, uint8_t *action, float *reward, uint8_t *done, float *W,
+             const float *clf, uint32_t enabled_mask, uint64_t t, uint32_t flags, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_step: null ctx");
+    if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_step: scg_set_map has not been called");
+    if (!x || !y || !vx || !vy || !option_id || !opt_steps || !ep_steps || !qcache || !action || !reward ||
+        !done || !W || !clf)
+        return fail(c, SCG_ERR_INVALID, "scg_step: null array argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    StepArgs A;
+    fill_common(c, A);
+    A.x = x; A.y = y; A.vx = vx; A.vy = vy;
+    A.option_id = option_id; A.opt_steps = opt_steps; A.ep_steps = ep_steps; A.qcache = qcache;
+    A.action = action; A.reward = reward; A.done = done;
+    A.W = W; A.clf = clf;
+    A.n = c->cfg.n_envs; A.k_lo = 0; A.k_hi = c->n_vf - 1;
+    A.enabled = enabled_mask; A.learn = (flags & SCG_STEP_LEARN) ? 1u : 0u; A.t = t;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->prof_on) {
+        if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
+        while (c->prof_ev->size() < c->prof_used + 2) {
+            hipEvent_t e;
+            SCG_HIP(c, hipEventCreate(&e));
+            c->prof_ev->push_back(e);
+        }
+        ev0 = (*c->prof_ev)[c->prof_used]; ev1 = (*c->prof_ev)[c->prof_used + 1];
+        c->prof_used += 2;
+        SCG_HIP(c, hipEventRecord(ev0, s));
+    }
+    hipLaunchKernelGGL(td_kernel<MODE_FUSED>, dim3(c->nblk), dim3(THREADS), LDS_BYTES, s, A);
+    SCG_HIP(c, hipGetLastError());
+    if (ev1) SCG_HIP(c, hipEventRecord(ev1, s));
+    if (flags & SCG_STEP_LEARN) return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s);
+    return SCG_OK;
+}
+
+int scg_profile_reset(scg_ctx *c, int32_t enable) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_profile_reset: null ctx");
+    c->prof_on = enable != 0;
+    c->prof_used = 0;
+    return SCG_OK;
+}
+
+int scg_profile_read(scg_ctx *c, double *kernel_ms_sum, int64_t *launches) {
+    if (!c || !kernel_ms_sum || !launches) return fail(c, SCG_ERR_INVALID, "scg_profile_read: null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+        SCG_HIP(c, hipEventSynchronize((*c->prof_ev)[i + 1]));
+        float ms = 0.0f;
+        SCG_HIP(c, hipEventElapsedTime(&ms, (*c->prof_ev)[i], (*c->prof_ev)[i + 1]));
+        sum += ms;
+    }
+    *kernel_ms_sum = sum;
+    *launches = (int64_t)(c->prof_used / 2);
+    return SCG_OK;
+}
+
+int scg_grad_buffers(scg_ctx *c, float **G, int32_t **n_k) {
+    if (!c || !G || !n_k) return fail(c, SCG_ERR_INVALID, "scg_grad_buffers: null argument");
+    *G = c->G_out; *n_k = c->nk_out;
+    return SCG_OK;
+}
+
+int scg_set_grad_buffers(scg_ctx *c, float *G, int32_t *n_k) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_grad_buffers: null ctx");
+    if ((G == nullptr) != (n_k == nullptr))
+        return fail(c, SCG_ERR_INVALID, "scg_set_grad_buffers: pass both buffers or neither");
+    c->G_out = G ? G : c->d_G;
+    c->nk_out = n_k ? n_k : c->d_nk;
+    return SCG_OK;
+}
+
+int scg_apply_update(scg_ctx *c, float *W, const float *G, const int32_t *n_k, void *stream) {
+    if (!c || !W || !G || !n_k) return fail(c, SCG_ERR_INVALID, "scg_apply_update: null argument");
+    if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update: scg_set_map has not been called (scale table)");
+    dim3 grid((NACT * NF + 255) / 256, c->n_vf);
+    hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G, n_k,
+                       c->d_scale, c->cfg.alpha);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_pinball_step(scg_ctx *c, int32_t n, float *x, float *y, float *vx, float *vy, const uint8_t *action,
+                     float *reward, uint8_t *goal, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_pinball_step: null ctx");
+    if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_pinball_step: scg_set_map has not been called");
+    if (n < 0 || !x || !y || !vx || !vy || !action || !reward || !goal)
+        return fail(c, SCG_ERR_INVALID, "scg_pinball_step: bad argument");
+    if (n == 0) return SCG_OK;
+    hipLaunchKernelGGL(pinball_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       n, x, y, vx, vy, action, reward, goal, c->d_edges, c->ms);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_fourier_features(scg_ctx *c, int32_t n, const float *x, const float *y, const float *vx,
+                         const float *vy, float *phi, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_fourier_features: null ctx");
+    if (n < 0 || !x || !y || !vx || !vy || !phi) return fail(c, SCG_ERR_INVALID, "scg_fourier_features: bad argument");
+    if (n == 0) return SCG_OK;
+    const int grid = n < 8192 ? n : 8192;
+    hipLaunchKernelGGL(features_kernel, dim3(grid), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), n, x, y,
+                       vx, vy, phi);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_q_values(scg_ctx *c, int32_t n, const float *x, const float *y, const float *vx, const float *vy,
+                 const float *Wk, float *q, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_q_values: null ctx");
+    if (n < 0 || !x || !y || !vx || !vy || !Wk || !q) return fail(c, SCG_ERR_INVALID, "scg_q_values: bad argument");
+    if (n == 0) return SCG_OK;
+    StepArgs A;
+    fill_common(c, A);
+    A.x = const_cast<float *>(x); A.y = const_cast<float *>(y);
+    A.vx = const_cast<float *>(vx); A.vy = const_cast<float *>(vy);
+    A.qcache = q; A.W = Wk; A.n = n; A.k_lo = 0; A.k_hi = 0; A.cnts = nullptr; A.learn = 0;
+    hipLaunchKernelGGL(td_kernel<MODE_QVAL>, dim3((n + BLOCK_ENVS - 1) / BLOCK_ENVS), dim3(THREADS), LDS_BYTES,
+                       reinterpret_cast<hipStream_t>(stream), A);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_q_update(scg_ctx *c, int32_t n, int32_t k, const float *x, const float *y, const float *vx,
+                 const float *vy, const uint8_t *action, const float *r, const float *cont, const float *xn,
+                 const float *yn, const float *vxn, const float *vyn, float *W, uint32_t flags, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_q_update: null ctx");
+    if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_q_update: scg_set_map has not been called (scale table)");
+    if (n < 0 || n > c->cfg.n_envs) return fail(c, SCG_ERR_INVALID, "scg_q_update: n must be in [0, n_envs]");
+    if (k < 0 || k >= c->n_vf) return fail(c, SCG_ERR_INVALID, "scg_q_update: VF index out of range");
+    if (!x || !y || !vx || !vy || !action || !r || !cont || !xn || !yn || !vxn || !vyn || !W)
+        return fail(c, SCG_ERR_INVALID, "scg_q_update: null array argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nblk = (n + BLOCK_ENVS - 1) / BLOCK_ENVS;
+    SCG_HIP(c, hipMemsetAsync(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t), s));
+    if (n > 0) {
+        StepArgs A;
+        fill_common(c, A);
+        A.x = const_cast<float *>(x); A.y = const_cast<float *>(y);
+        A.vx = const_cast<float *>(vx); A.vy = const_cast<float *>(vy);
+        A.action = const_cast<uint8_t *>(action); A.reward = const_cast<float *>(r); A.cont_in = cont;
+        A.xn = xn; A.yn = yn; A.vxn = vxn; A.vyn = vyn;
+        A.W = W; A.n = n; A.k_lo = k; A.k_hi = k; A.learn = 1;
+        hipLaunchKernelGGL(td_kernel<MODE_TRANS>, dim3(nblk), dim3(THREADS), LDS_BYTES, s, A);
+        SCG_HIP(c, hipGetLastError());
+    }
+    return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, nblk, s);
+}
+
+int scg_classifier_predict(scg_ctx *c, int32_t n, const float *x, const float *y, const float *w8, uint8_t *out,
+                           void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_classifier_predict: null ctx");
+    if (n < 0 || !x || !y || !w8 || !out) return fail(c, SCG_ERR_INVALID, "scg_classifier_predict: bad argument");
+    if (n == 0) return SCG_OK;
+    hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       n, x, y, w8, out);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_fit_initiation(scg_ctx *c, int32_t n_fit, const float *xy, const uint8_t *label, const int32_t *offsets,
+                       float *w, int32_t iters, float lr, float l2, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_fit_initiation: null ctx");
+    if (n_fit < 0 || iters < 0 || !xy || !label || !offsets || !w)
+        return fail(c, SCG_ERR_INVALID, "scg_fit_initiation: bad argument");
+    if (n_fit == 0 || iters == 0) return SCG_OK;
+    hipLaunchKernelGGL(fit_kernel, dim3(n_fit), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), xy, label,
+                       offsets, w, iters, lr, l2);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/scg_abi.h declares;
+error behaviour that needs no device is checked too. No compute call is made."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "scg_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(scg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert declared_symbols() == sorted(pkg.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.scg_abi_version() == 1
+    assert lib.scg_strerror(0) == b"ok" and b"invalid" in lib.scg_strerror(-1)
+
+
+def test_create_rejects_bad_config_without_touching_a_device(pkg):
+    from skill_chaining_with_graphs_amd._lib import ScgConfig
+    lib = pkg.load_library()
+    ctx = C.c_void_p()
+    bad = [dict(n_envs=0), dict(n_options=6), dict(n_options=-1), dict(fourier_order=3)]
+    for kw in bad:
+        cfg = dict(n_envs=4, n_options=0, fourier_order=5, device=0)
+        cfg.update(kw)
+        assert lib.scg_create(C.byref(ctx), C.byref(ScgConfig(**cfg))) == -1
+        assert not ctx.value and lib.scg_last_error(None)
+    assert lib.scg_create(None, None) == -1
+    assert lib.scg_destroy(None) == 0
+    assert lib.scg_step(None, *([None] * 13), 0, 0, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    from skill_chaining_with_graphs_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libscg_hip.so")
+    with pytest.raises(_lib.ScgError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pk = os.path.join(ROOT, "skill-chaining-with-graphs_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "sc_oracle" not in src and "oracle/" not in src, os.path.join(dp, f)
