@@ -98,7 +98,7 @@ def test_fused_step_rollout_bit_exact(map_name, n, n_options, steps):
     if n > 1:
         x, y, vx, vy = random_states(m, n, 10, vmax=1.0)
         st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
-        st_o["ep_steps"][:] = np.random.default_rng(11).integers(0, 50, n)
+        st_o["ep_steps"][:] = np.random.default_rng(11).integers(0, 59, n)
     W_o = random_weights(n_options + 1, 12, std=0.05)
     st_d = state_to_device(st_o, ctx)
     W_d, clf_d = dev(W_o.copy()), dev(clf)
