@@ -30,7 +30,8 @@ constexpr int OFF_POW = OFF_INT + 4 * BLOCK_ENVS;              // float2 pow[256
 constexpr int OFF_AB = OFF_POW + BLOCK_ENVS * 2 * 20 * 8;      // float2 ab[8][2][36]
 constexpr int OFF_BUF = OFF_AB + WAVES * 2 * 36 * 8;           // float buf[5*1296]
 constexpr int OFF_LIST = OFF_BUF + NACT * NF * 4;              // uint16 list[256]
-constexpr int OFF_MISC = OFF_LIST + BLOCK_ENVS * 2;            // int misc[16]
+constexpr int OFF_DELTA = OFF_LIST + BLOCK_ENVS * 2;           // float delta[256] (per item)
+constexpr int OFF_MISC = OFF_DELTA + BLOCK_ENVS * 4;           // int misc[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_POW % 16 == 0 && OFF_AB % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     float2 *s_ab = reinterpret_cast<float2 *>(smem + OFF_AB);
     float *s_buf = reinterpret_cast<float *>(smem + OFF_BUF);
     uint16_t *s_list = reinterpret_cast<uint16_t *>(smem + OFF_LIST);
+    float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,11 +276,10 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         w_rsrc, (t < 2 || v20) ? w_vt : 0u, kbase + (uint32_t)(a * NF + 576 * t) * 4u, 0));
                     Wr[a][18 + t] = (t < 2 || v20) ? v : 0.0f;
                 }
-#pragma unroll
-                for (int j = 0; j < NSLOT; ++j) dW[a][j] = 0.0f;
             }
         }
 
+        // ---- loop 1 (W_k live): Q(s_next,.) -> qcache, Q(s,a), TD error -> s_delta[item]
         for (int it = wave; it < m; it += WAVES) {
             const int i = __builtin_amdgcn_readfirstlane((int)s_list[it]);
             const int ot = s_ot[i], on = s_on[i];
@@ -339,6 +340,33 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, q[a]);
                 const float target = tgt ? fmaf(cont, mx, r) : r;
                 const float delta = target - qsa;
+                if (lane == 0) s_delta[it] = delta;      // read back by this same wave in loop 2
+            }
+            wave_lds_sync();
+        }
+
+        if (MODE == MODE_QVAL || nupd == 0) continue;
+
+        // ---- loop 2 (W_k dead, accumulator live): acc[a_t][f] = fma(delta, phi_f(s), acc[a_t][f]).
+        // Splitting the pass keeps W (105 VGPRs) and the accumulator (105 VGPRs) from being live together;
+        // held together they spilled ~80 VGPRs to scratch inside the item loop (17x slower).
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) dW[a][j] = 0.0f;
+        }
+        for (int it = wave; it < m; it += WAVES) {
+            const int i = __builtin_amdgcn_readfirstlane((int)s_list[it]);
+            const int ot = s_ot[i];
+            const bool u = A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
+            if (!u) continue;
+            const float2 *pw_s = s_pow + (i * 2 + 0) * 20;
+            if (lane < 36) abw[lane] = cmul(pow_at(pw_s, 0, c1p), pow_at(pw_s, 1, c2p));
+            wave_lds_sync();
+            const int at = s_a[i];
+            const float delta = s_delta[it];
+            const float2 cdm = cmul(pow_at(pw_s, 2, c3m), pow_at(pw_s, 3, c4m));
+            const float2 cdt = cmul(pow_at(pw_s, 2, 5), pow_at(pw_s, 3, c4t));
 #define SCG_UPD_CASE(AA)                                                   \
     case AA:                                                               \
         _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
@@ -346,18 +374,16 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             dW[AA][j] = fmaf(delta, ph, dW[AA][j]);                        \
         }                                                                  \
         break;
-                switch (at) { SCG_UPD_CASE(0) SCG_UPD_CASE(1) SCG_UPD_CASE(2) SCG_UPD_CASE(3) default:
-                    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
-                        SCG_PHI(j, 0, ph)
-                        dW[4][j] = fmaf(delta, ph, dW[4][j]);
-                    }
-                    break; }
+            switch (at) { SCG_UPD_CASE(0) SCG_UPD_CASE(1) SCG_UPD_CASE(2) SCG_UPD_CASE(3) default:
+                _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
+                    SCG_PHI(j, 0, ph)
+                    dW[4][j] = fmaf(delta, ph, dW[4][j]);
+                }
+                break; }
 #undef SCG_UPD_CASE
-            }
             wave_lds_sync();
         }
 
-        if (MODE == MODE_QVAL || nupd == 0) continue;
         // block partial: ((acc_0 + acc_1) + ...) + acc_7, through LDS in wave order
         for (int w = 0; w < WAVES; ++w) {
             if (wave == w) {
