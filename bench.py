@@ -80,7 +80,7 @@ def cpu_baseline(seconds_target=15.0):
     orc.apply(W, G, nk)
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < seconds_target and steps < 1000:
+    while time.perf_counter() - t0 < seconds_target and steps < 100000:
         G, nk = orc.step(st, W, clf, steps + 1)
         orc.apply(W, G, nk)
         steps += 1
@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--options", type=int, default=N_OPTIONS)
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-learn", action="store_true", help="diagnostic: act + physics + qcache only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -139,13 +140,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    learn = not args.no_learn
     for _ in range(args.warmup):
-        agent.step_batch()
+        agent.step_batch(learn)
     barrier()
     lib.scg_profile_reset(ctx, 1)                 # HIP events round the fused kernel, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        agent.step_batch()
+        agent.step_batch(learn)
     barrier()
     dt = time.perf_counter() - t0
     import ctypes as C

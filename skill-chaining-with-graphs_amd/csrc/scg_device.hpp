@@ -75,9 +75,19 @@ __device__ __forceinline__ float2 pow_at(const float2 *pw, int d, int k) {   // 
 }
 
 // ------------------------------------------------------------------ SPEC §3.1 butterfly
+// for m in (1,2,4,8,16,32): v_l = v_l + v_(l xor m). Stages 1..8 are DPP adds inside a 16-lane row
+// (after stages 1,2 a quad is uniform, so row_half_mirror == xor 4; after stage 4, row_mirror == xor 8);
+// stages 16 and 32 use gfx950's v_permlane16_swap / v_permlane32_swap: with both operands = v they return
+// the two partner rows / halves, whose (commutative) sum is the same bits in both partners. No LDS.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v = v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
     return v;
 }
 

@@ -27,11 +27,12 @@ constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][256
 constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [256]
 constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [256] (+pad)
 constexpr int OFF_POW = OFF_INT + 4 * BLOCK_ENVS;              // float2 pow[256][2][20]
-constexpr int OFF_AB = OFF_POW + BLOCK_ENVS * 2 * 20 * 8;      // float2 ab[8][2][36]
-constexpr int OFF_BUF = OFF_AB + WAVES * 2 * 36 * 8;           // float buf[5*1296]
+constexpr int OFF_AB = OFF_POW + BLOCK_ENVS * 2 * 20 * 8;      // float2 ab[8][36]
+constexpr int OFF_BUF = OFF_AB + WAVES * 36 * 8;               // float buf[5*1296]
 constexpr int OFF_LIST = OFF_BUF + NACT * NF * 4;              // uint16 list[256]
 constexpr int OFF_DELTA = OFF_LIST + BLOCK_ENVS * 2;           // float delta[256] (per item)
-constexpr int OFF_MISC = OFF_DELTA + BLOCK_ENVS * 4;           // int misc[16]
+constexpr int OFF_MAXQ = OFF_DELTA + BLOCK_ENVS * 4;           // float maxq[256] (per item)
+constexpr int OFF_MISC = OFF_MAXQ + BLOCK_ENVS * 4;            // int misc[16]
 constexpr int LDS_BYTES = OFF_MISC + 64;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_POW % 16 == 0 && OFF_AB % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     float *s_buf = reinterpret_cast<float *>(smem + OFF_BUF);
     uint16_t *s_list = reinterpret_cast<uint16_t *>(smem + OFF_LIST);
     float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
+    float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -210,28 +212,33 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 
     // Per-lane base pointers; every access below is base[compile-time constant], so the address is one
     // VGPR + an immediate (hipcc otherwise materialises ~100 separate addresses and spills them).
-    float2 *abw = s_ab + wave * 72;                       // [0..35] = AB(s), [36..71] = AB(s_next)
-    const float2 *ab_m = abw + hi;                        // main slots:  ab_m[36*sigma + 2j]
-    const float2 *ab_t = abw + tl;                        // tail slots 18,19: ab_t[36*sigma + 16t]
+    float2 *abw = s_ab + wave * 36;                       // this wave's AB table of the item in flight
+    const float2 *ab_m = abw + hi;                        // main slots:  ab_m[2j]
+    const float2 *ab_t = abw + tl;                        // tail slots 18,19: ab_t[16t]
     const float2 *ab_t2 = abw + min(32 + tl, 35);         // tail slot 20 (clamped; masked by v20)
     float *buf_m = s_buf + hi * 36 + col;                 // buf_m[a*NF + 72j]
     float *buf_t = s_buf + tl * 36 + 32 + (lane & 3);     // buf_t[a*NF + 576t]
     const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets, same split
     const uint32_t w_vt = (uint32_t)(tl * 36 + 32 + (lane & 3)) * 4u;
 
-    float Wr[NACT][NSLOT], dW[NACT][NSLOT];
+    // R = W_k in loops A and B, the gradient accumulator in loop C: the two are never live together
+    // (held together, 2 x 105 VGPRs + working set spilled ~80 registers inside the item loop).
+    float R[NACT][NSLOT];
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(A.W), 0, (MODE == MODE_QVAL ? 1 : A.n_vf) * NACT * NF * 4, 0x00020000);
 
-// phi of slot J for state SG (0 = s, 1 = s_next) given that state's column factors cdm / cdt
-#define SCG_PHI(J, SG, PH)                                                                   \
-    float PH;                                                                                \
-    {                                                                                        \
-        const float2 ab_ = (J) < 18 ? ab_m[36 * (SG) + 2 * (J)]                              \
-                                    : ((J) < 20 ? ab_t[36 * (SG) + 16 * ((J)-18)] : ab_t2[36 * (SG)]); \
-        const float2 cd_ = (J) < 18 ? cdm : cdt;                                             \
-        PH = fmaf(-ab_.y, cd_.y, ab_.x * cd_.x);                                             \
-        if ((J) == 20) PH = v20 ? PH : 0.0f;                                                 \
+// all 21 AB factors of the item in flight -> registers, in one burst of LDS reads
+#define SCG_LOAD_AB(ABV)                                                  \
+    float2 ABV[NSLOT];                                                    \
+    _Pragma("unroll") for (int j_ = 0; j_ < 18; ++j_) ABV[j_] = ab_m[2 * j_]; \
+    ABV[18] = ab_t[0]; ABV[19] = ab_t[16]; ABV[20] = ab_t2[0];
+// phi of slot J from the prefetched AB factors and the lane's two column factors cdm / cdt
+#define SCG_PHI(J, ABV, PH)                                               \
+    float PH;                                                             \
+    {                                                                     \
+        const float2 cd_ = (J) < 18 ? cdm : cdt;                          \
+        PH = fmaf(-ABV[J].y, cd_.y, ABV[J].x * cd_.x);                    \
+        if ((J) == 20) PH = v20 ? PH : 0.0f;                              \
     }
 
     // ------------------------------------------------------------------ phase TD, VF by VF (SPEC §5)
@@ -268,120 +275,158 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             for (int a = 0; a < NACT; ++a) {
 #pragma unroll
                 for (int j = 0; j < 18; ++j)
-                    Wr[a][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    R[a][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                         w_rsrc, w_vm, kbase + (uint32_t)(a * NF + 72 * j) * 4u, 0));
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                         w_rsrc, (t < 2 || v20) ? w_vt : 0u, kbase + (uint32_t)(a * NF + 576 * t) * 4u, 0));
-                    Wr[a][18 + t] = (t < 2 || v20) ? v : 0.0f;
+                    R[a][18 + t] = (t < 2 || v20) ? v : 0.0f;
                 }
             }
         }
 
-        // ---- loop 1 (W_k live): Q(s_next,.) -> qcache, Q(s,a), TD error -> s_delta[item]
-        for (int it = wave; it < m; it += WAVES) {
-            const int i = __builtin_amdgcn_readfirstlane((int)s_list[it]);
-            const int ot = s_ot[i], on = s_on[i];
-            const bool u = (MODE != MODE_QVAL) && A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
-            const bool cache = (on == k);
-            const float r = (k == 0) ? s_r0[i] : s_ro[i];
-            const float cont = (k == 0) ? s_c0[i] : s_co[i];
-            const bool tgt = u && cont > 0.0f;
-            const bool ev = tgt || cache;
-            const float2 *pw_s = s_pow + (i * 2 + 0) * 20;
-            const float2 *pw_n = s_pow + (i * 2 + 1) * 20;
-            if (lane < 36) {
-                if (ev) abw[36 + lane] = cmul(pow_at(pw_n, 0, c1p), pow_at(pw_n, 1, c2p));
-                if (u) abw[lane] = cmul(pow_at(pw_s, 0, c1p), pow_at(pw_s, 1, c2p));
-            }
-            wave_lds_sync();
-            float q[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            if (ev) {
-                const float2 cdm = cmul(pow_at(pw_n, 2, c3m), pow_at(pw_n, 3, c4m));
-                const float2 cdt = cmul(pow_at(pw_n, 2, 5), pow_at(pw_n, 3, c4t));
+        // wave-uniform item predicates (LDS broadcast reads, forced into SGPRs)
+        auto item_env = [&](int it) { return __builtin_amdgcn_readfirstlane((int)s_list[it]); };
+        auto is_upd = [&](int i) {
+            return (MODE != MODE_QVAL) && A.learn &&
+                   ((MODE == MODE_FUSED && k == 0) || __builtin_amdgcn_readfirstlane((int)s_ot[i]) == k);
+        };
+        auto item_cont = [&](int i) {
+            return __builtin_amdgcn_readfirstlane(__float_as_int((k == 0) ? s_c0[i] : s_co[i]));
+        };
+        auto wants_eval = [&](int it) {
+            const int i = item_env(it);
+            const bool cache = __builtin_amdgcn_readfirstlane((int)s_on[i]) == k;
+            return cache || (is_upd(i) && __int_as_float(item_cont(i)) > 0.0f);
+        };
+        auto wants_upd = [&](int it) { return is_upd(item_env(it)); };
+        // AB table of (env i, state sg) -> this wave's LDS scratch (lanes 0..35, one product each)
+        auto gen_ab = [&](int i, int sg) {
+            const float2 *pw = s_pow + (i * 2 + sg) * 20;
+            if (lane < 36) abw[lane] = cmul(pow_at(pw, 0, c1p), pow_at(pw, 1, c2p));
+        };
+
+        // ---- loop A (W_k live): Q_k(s_next, .) -> qcache, max -> s_maxq[item].
+        // Software-pipelined: the next item's AB table is written to LDS while this item's FMAs run.
+        {
+            int it = wave;
+            while (it < m && !wants_eval(it)) it += WAVES;
+            if (it < m) gen_ab(item_env(it), 1);
+            while (it < m) {
+                const int i = item_env(it);
+                const float2 *pw = s_pow + (i * 2 + 1) * 20;
+                wave_lds_sync();
+                SCG_LOAD_AB(abv)
+                const float2 cdm = cmul(pow_at(pw, 2, c3m), pow_at(pw, 3, c4m));
+                const float2 cdt = cmul(pow_at(pw, 2, 5), pow_at(pw, 3, c4t));
+                int nx = it + WAVES;
+                while (nx < m && !wants_eval(nx)) nx += WAVES;
+                wave_lds_sync();
+                if (nx < m) gen_ab(item_env(nx), 1);
+                float q[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int j = 0; j < NSLOT; ++j) {
-                    SCG_PHI(j, 1, ph)
+                    SCG_PHI(j, abv, ph)
 #pragma unroll
-                    for (int a = 0; a < NACT; ++a) q[a] = fmaf(Wr[a][j], ph, q[a]);
+                    for (int a = 0; a < NACT; ++a) q[a] = fmaf(R[a][j], ph, q[a]);
                 }
 #pragma unroll
                 for (int a = 0; a < NACT; ++a) q[a] = wave_sum(q[a]);
+                const bool cache = __builtin_amdgcn_readfirstlane((int)s_on[i]) == k;
                 if (cache && lane < NACT) {
                     const float v = lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : lane == 3 ? q[3] : q[4];
                     A.qcache[(size_t)lane * N + e0 + i] = v;
                 }
+                float mx = q[0];
+#pragma unroll
+                for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, q[a]);
+                if (lane == 0) s_maxq[it] = mx;          // read back by this same wave in loop B
+                it = nx;
             }
-            if (u) {
-                const int at = s_a[i];
-                const float2 cdm = cmul(pow_at(pw_s, 2, c3m), pow_at(pw_s, 3, c4m));
-                const float2 cdt = cmul(pow_at(pw_s, 2, 5), pow_at(pw_s, 3, c4t));
-                // phi(s) is evaluated twice (for Q(s,a), then for the accumulate) instead of being held in
-                // 21 VGPRs across the butterfly: W + dW already take 210 of the 256 registers.
+        }
+        if (MODE == MODE_QVAL || nupd == 0) continue;
+
+        // ---- loop B (W_k live): Q_k(s, a_t), TD error -> s_delta[item]
+        {
+            int it = wave;
+            while (it < m && !wants_upd(it)) it += WAVES;
+            if (it < m) gen_ab(item_env(it), 0);
+            while (it < m) {
+                const int i = item_env(it);
+                const float2 *pw = s_pow + (i * 2 + 0) * 20;
+                wave_lds_sync();
+                SCG_LOAD_AB(abv)
+                const float2 cdm = cmul(pow_at(pw, 2, c3m), pow_at(pw, 3, c4m));
+                const float2 cdt = cmul(pow_at(pw, 2, 5), pow_at(pw, 3, c4t));
+                int nx = it + WAVES;
+                while (nx < m && !wants_upd(nx)) nx += WAVES;
+                wave_lds_sync();
+                if (nx < m) gen_ab(item_env(nx), 0);
+                const int at = __builtin_amdgcn_readfirstlane((int)s_a[i]);
                 float qsa = 0.0f;
 #define SCG_QSA_CASE(AA)                                                   \
     case AA:                                                               \
         _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
-            SCG_PHI(j, 0, ph)                                              \
-            qsa = fmaf(Wr[AA][j], ph, qsa);                                \
+            SCG_PHI(j, abv, ph)                                            \
+            qsa = fmaf(R[AA][j], ph, qsa);                                 \
         }                                                                  \
         break;
                 switch (at) { SCG_QSA_CASE(0) SCG_QSA_CASE(1) SCG_QSA_CASE(2) SCG_QSA_CASE(3) default:
                     _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
-                        SCG_PHI(j, 0, ph)
-                        qsa = fmaf(Wr[4][j], ph, qsa);
+                        SCG_PHI(j, abv, ph)
+                        qsa = fmaf(R[4][j], ph, qsa);
                     }
                     break; }
 #undef SCG_QSA_CASE
                 qsa = wave_sum(qsa);
-                float mx = q[0];
-#pragma unroll
-                for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, q[a]);
-                const float target = tgt ? fmaf(cont, mx, r) : r;
-                const float delta = target - qsa;
-                if (lane == 0) s_delta[it] = delta;      // read back by this same wave in loop 2
+                const float r = (k == 0) ? s_r0[i] : s_ro[i];
+                const float cont = __int_as_float(item_cont(i));
+                const float target = cont > 0.0f ? fmaf(cont, s_maxq[it], r) : r;
+                if (lane == 0) s_delta[it] = target - qsa;     // read back by this same wave in loop C
+                it = nx;
             }
-            wave_lds_sync();
         }
 
-        if (MODE == MODE_QVAL || nupd == 0) continue;
-
-        // ---- loop 2 (W_k dead, accumulator live): acc[a_t][f] = fma(delta, phi_f(s), acc[a_t][f]).
-        // Splitting the pass keeps W (105 VGPRs) and the accumulator (105 VGPRs) from being live together;
-        // held together they spilled ~80 VGPRs to scratch inside the item loop (17x slower).
+        // ---- loop C (accumulator live): acc[a_t][f] = fma(delta, phi_f(s), acc[a_t][f])
 #pragma unroll
         for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-            for (int j = 0; j < NSLOT; ++j) dW[a][j] = 0.0f;
+            for (int j = 0; j < NSLOT; ++j) R[a][j] = 0.0f;
         }
-        for (int it = wave; it < m; it += WAVES) {
-            const int i = __builtin_amdgcn_readfirstlane((int)s_list[it]);
-            const int ot = s_ot[i];
-            const bool u = A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
-            if (!u) continue;
-            const float2 *pw_s = s_pow + (i * 2 + 0) * 20;
-            if (lane < 36) abw[lane] = cmul(pow_at(pw_s, 0, c1p), pow_at(pw_s, 1, c2p));
-            wave_lds_sync();
-            const int at = s_a[i];
-            const float delta = s_delta[it];
-            const float2 cdm = cmul(pow_at(pw_s, 2, c3m), pow_at(pw_s, 3, c4m));
-            const float2 cdt = cmul(pow_at(pw_s, 2, 5), pow_at(pw_s, 3, c4t));
+        {
+            int it = wave;
+            while (it < m && !wants_upd(it)) it += WAVES;
+            if (it < m) gen_ab(item_env(it), 0);
+            while (it < m) {
+                const int i = item_env(it);
+                const float2 *pw = s_pow + (i * 2 + 0) * 20;
+                wave_lds_sync();
+                SCG_LOAD_AB(abv)
+                const float2 cdm = cmul(pow_at(pw, 2, c3m), pow_at(pw, 3, c4m));
+                const float2 cdt = cmul(pow_at(pw, 2, 5), pow_at(pw, 3, c4t));
+                int nx = it + WAVES;
+                while (nx < m && !wants_upd(nx)) nx += WAVES;
+                wave_lds_sync();
+                if (nx < m) gen_ab(item_env(nx), 0);
+                const int at = __builtin_amdgcn_readfirstlane((int)s_a[i]);
+                const float delta = s_delta[it];
 #define SCG_UPD_CASE(AA)                                                   \
     case AA:                                                               \
         _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
-            SCG_PHI(j, 0, ph)                                              \
-            dW[AA][j] = fmaf(delta, ph, dW[AA][j]);                        \
+            SCG_PHI(j, abv, ph)                                            \
+            R[AA][j] = fmaf(delta, ph, R[AA][j]);                          \
         }                                                                  \
         break;
-            switch (at) { SCG_UPD_CASE(0) SCG_UPD_CASE(1) SCG_UPD_CASE(2) SCG_UPD_CASE(3) default:
-                _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
-                    SCG_PHI(j, 0, ph)
-                    dW[4][j] = fmaf(delta, ph, dW[4][j]);
-                }
-                break; }
+                switch (at) { SCG_UPD_CASE(0) SCG_UPD_CASE(1) SCG_UPD_CASE(2) SCG_UPD_CASE(3) default:
+                    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
+                        SCG_PHI(j, abv, ph)
+                        R[4][j] = fmaf(delta, ph, R[4][j]);
+                    }
+                    break; }
 #undef SCG_UPD_CASE
-            wave_lds_sync();
+                it = nx;
+            }
         }
 
         // block partial: ((acc_0 + acc_1) + ...) + acc_7, through LDS in wave order
@@ -392,13 +437,13 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 #pragma unroll
                     for (int j = 0; j < 18; ++j) {
                         float *p = &buf_m[a * NF + 72 * j];
-                        *p = (w == 0) ? dW[a][j] : *p + dW[a][j];
+                        *p = (w == 0) ? R[a][j] : *p + R[a][j];
                     }
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         if (t < 2 || v20) {
                             float *p = &buf_t[a * NF + 576 * t];
-                            *p = (w == 0) ? dW[a][18 + t] : *p + dW[a][18 + t];
+                            *p = (w == 0) ? R[a][18 + t] : *p + R[a][18 + t];
                         }
                     }
                 }
@@ -409,6 +454,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         for (int f = tid; f < NACT * NF; f += THREADS) slab[f] = s_buf[f];
     }
 #undef SCG_PHI
+#undef SCG_LOAD_AB
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,34 +471,54 @@ struct ReduceArgs {
     uint32_t apply;
 };
 
-__global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs R) {
-    __shared__ int s_cnt[256];
+constexpr int RED_THREADS = 64;
+__global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
+    __shared__ int s_cnt[RED_THREADS];
     const int k = blockIdx.y;
     const int tid = threadIdx.x;
     int c = 0;
-    for (int b = tid; b < R.nblk; b += 256) c += R.cnts[(size_t)b * R.n_vf + k];
+    for (int b = tid; b < R.nblk; b += RED_THREADS) c += R.cnts[(size_t)b * R.n_vf + k];
     s_cnt[tid] = c;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
         if (tid < s) s_cnt[tid] += s_cnt[tid + s];
         __syncthreads();
     }
     const int nk = s_cnt[0];
-    const int i = blockIdx.x * 256 + tid;
     if (blockIdx.x == 0 && tid == 0) R.n_k[k] = nk;
-    if (i >= NACT * NF) return;
-    float S = 0.0f;
-    const size_t stride = (size_t)R.n_vf * NACT * NF;
-    const float *p = R.slabs + (size_t)k * NACT * NF + i;
-    for (int b = 0; b < R.nblk; ++b) {
-        if (R.cnts[(size_t)b * R.n_vf + k] > 0) S = S + p[(size_t)b * stride];
+    // one float4 (4 consecutive weights) per thread; the sum over blocks stays strictly in block order
+    // (SPEC §5) but the loads of 16 slabs are in flight together — the kernel is a 26 KB x nblk x n_vf stream.
+    const int i4 = blockIdx.x * RED_THREADS + tid;
+    if (i4 >= NACT * NF / 4) return;
+    float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const size_t stride4 = (size_t)R.n_vf * NACT * NF / 4;
+    const float4 *p = reinterpret_cast<const float4 *>(R.slabs) + (size_t)k * (NACT * NF / 4) + i4;
+    constexpr int U = 16;
+    for (int b0 = 0; b0 < R.nblk; b0 += U) {
+        float4 v[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u;
+            on[u] = b < R.nblk && R.cnts[(size_t)b * R.n_vf + k] > 0;     // wave-uniform
+            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (on[u]) v[u] = p[(size_t)b * stride4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (on[u]) { S.x = S.x + v[u].x; S.y = S.y + v[u].y; S.z = S.z + v[u].z; S.w = S.w + v[u].w; }
+        }
     }
-    R.G[(size_t)k * NACT * NF + i] = S;
+    reinterpret_cast<float4 *>(R.G)[(size_t)k * (NACT * NF / 4) + i4] = S;
     if (R.apply && nk > 0) {
         const float step = R.alpha / (float)nk;
-        const int f = i % NF;
-        float *w = R.W + (size_t)k * NACT * NF + i;
-        *w = fmaf(step * R.scale[f], S, *w);
+        const int f = (i4 * 4) % NF;                                       // NF % 4 == 0: no row straddling
+        const float4 sc = *reinterpret_cast<const float4 *>(R.scale + f);
+        float4 *wp = reinterpret_cast<float4 *>(R.W) + (size_t)k * (NACT * NF / 4) + i4;
+        float4 w = *wp;
+        w.x = fmaf(step * sc.x, S.x, w.x); w.y = fmaf(step * sc.y, S.y, w.y);
+        w.z = fmaf(step * sc.z, S.z, w.z); w.w = fmaf(step * sc.w, S.w, w.w);
+        *wp = w;
     }
 }
 
@@ -713,8 +779,8 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
     ReduceArgs R;
     R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
     R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
-    dim3 grid((NACT * NF + 255) / 256, c->n_vf);
-    hipLaunchKernelGGL(reduce_kernel, grid, dim3(256), 0, s, R);
+    dim3 grid((NACT * NF / 4 + RED_THREADS - 1) / RED_THREADS, c->n_vf);
+    hipLaunchKernelGGL(reduce_kernel, grid, dim3(RED_THREADS), 0, s, R);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
