@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learn", action="store_true", help="diagnostic: act + physics + qcache only")
+    ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -141,6 +142,18 @@ def main():
         torch.cuda.synchronize()
 
     learn = not args.no_learn
+    if args.diag_no_td:
+        import ctypes as _C
+        from skill_chaining_with_graphs_amd.core import _ptr
+        def _step(_learn=True):
+            st = agent.state
+            agent.ctx._call("scg_step", _ptr(st.x), _ptr(st.y), _ptr(st.vx), _ptr(st.vy), _ptr(st.option_id),
+                            _ptr(st.opt_steps), _ptr(st.ep_steps), _ptr(st.qcache), _ptr(st.action),
+                            _ptr(st.reward), _ptr(st.done), _ptr(agent.W), _ptr(agent.clf),
+                            _C.c_uint32(agent.enabled_mask), _C.c_uint64(agent.t), _C.c_uint32(0x100),
+                            agent.ctx._stream())
+            agent.t += 1
+        agent.step_batch = _step
     for _ in range(args.warmup):
         agent.step_batch(learn)
     barrier()

@@ -802,6 +802,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     A.W = W; A.clf = clf;
     A.n = c->cfg.n_envs; A.k_lo = 0; A.k_hi = c->n_vf - 1;
     A.enabled = enabled_mask; A.learn = (flags & SCG_STEP_LEARN) ? 1u : 0u; A.t = t;
+    if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof_on) {
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
