@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learn", action="store_true", help="diagnostic: act + physics + qcache only")
     ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
+    ap.add_argument("--diag-exit", type=int, default=0, help="diagnostic: 1 = exit before phase P, 2 = after phase P")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -142,7 +143,7 @@ def main():
         torch.cuda.synchronize()
 
     learn = not args.no_learn
-    if args.diag_no_td:
+    if args.diag_no_td or args.diag_exit:
         import ctypes as _C
         from skill_chaining_with_graphs_amd.core import _ptr
         def _step(_learn=True):
@@ -150,7 +151,7 @@ def main():
             agent.ctx._call("scg_step", _ptr(st.x), _ptr(st.y), _ptr(st.vx), _ptr(st.vy), _ptr(st.option_id),
                             _ptr(st.opt_steps), _ptr(st.ep_steps), _ptr(st.qcache), _ptr(st.action),
                             _ptr(st.reward), _ptr(st.done), _ptr(agent.W), _ptr(agent.clf),
-                            _C.c_uint32(agent.enabled_mask), _C.c_uint64(agent.t), _C.c_uint32(0x100),
+                            _C.c_uint32(agent.enabled_mask), _C.c_uint64(agent.t), _C.c_uint32(0x100 | (args.diag_exit << 12)),
                             agent.ctx._stream())
             agent.t += 1
         agent.step_batch = _step

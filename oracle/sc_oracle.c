@@ -250,32 +250,43 @@ typedef struct {
 static void block_vf_pass(const float *Wk, int n_items, const td_item *items, const env_rec *rec,
                           const float *phi_s, const float *phi_n, float *qcache, int qstride,
                           int env0, float *Pout, int *n_upd) {
-    /* acc[wave][a][f] */
+    /* acc[wave][a][f]. Evaluations first (order-free: each item's Q values depend on nothing else). */
     float *acc = (float *)calloc((size_t)SCO_WAVES * NACT * NF, sizeof(float));
+    float *maxq = (float *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(float));
     int cnt = 0;
     for (int i = 0; i < n_items; ++i) {
         const td_item *it = &items[i];
-        int w = i % SCO_WAVES;
-        const env_rec *r = &rec[it->env];
-        float qn[NACT] = {0, 0, 0, 0, 0};
         if (it->tgt || it->cache) {
+            float qn[NACT];
             const float *pn = phi_n + (size_t)it->env * NF;
             for (int a = 0; a < NACT; ++a) qn[a] = wave_dot(Wk + a * NF, pn);
             if (it->cache)
                 for (int a = 0; a < NACT; ++a) qcache[(size_t)a * qstride + env0 + it->env] = qn[a];
-        }
-        if (it->upd) {
-            const float *ps = phi_s + (size_t)it->env * NF;
-            float qsa = wave_dot(Wk + r->a * NF, ps);
             float m = qn[0];
             for (int a = 1; a < NACT; ++a) m = fmaxf(m, qn[a]);
-            float target = it->tgt ? fmaf(it->cont, m, it->r) : it->r;
+            maxq[i] = m;
+        }
+    }
+    /* SPEC §5: update items sorted by (action, env); quads of 4 within an action run; quad q -> wave q mod 8 */
+    int q = 0;
+    for (int act = 0; act < NACT; ++act) {
+        int in_run = 0;
+        for (int i = 0; i < n_items; ++i) {
+            const td_item *it = &items[i];
+            const env_rec *r = &rec[it->env];
+            if (!it->upd || r->a != act) continue;
+            int w = (q + in_run / 4) % SCO_WAVES;
+            const float *ps = phi_s + (size_t)it->env * NF;
+            float qsa = wave_dot(Wk + r->a * NF, ps);
+            float target = it->tgt ? fmaf(it->cont, maxq[i], it->r) : it->r;
             float delta = target - qsa;
             float *dst = acc + ((size_t)w * NACT + r->a) * NF;
             for (int f = 0; f < NF; ++f) dst[f] = fmaf(delta, ps[f], dst[f]);
-            ++cnt;
+            ++cnt; ++in_run;
         }
+        q += (in_run + 3) / 4;
     }
+    free(maxq);
     for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
         float s = acc[i];
         for (int w = 1; w < SCO_WAVES; ++w) s = s + acc[(size_t)w * NACT * NF + i];
@@ -283,6 +294,22 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
     }
     free(acc);
     *n_upd = cnt;
+}
+
+
+/* SPEC §5: G = ((T_0 + T_1) + ...), T_s = ((P_16s + P_16s+1) + ...) over the blocks of segment s */
+#define SCO_SEG 16
+static float seg_sum(const float *P, size_t stride, size_t idx, int nblk) {
+    float g = 0.0f;
+    int first = 1;
+    for (int s0 = 0; s0 < nblk; s0 += SCO_SEG) {
+        float t = P[(size_t)s0 * stride + idx];
+        int s1 = s0 + SCO_SEG < nblk ? s0 + SCO_SEG : nblk;
+        for (int b = s0 + 1; b < s1; ++b) t = t + P[(size_t)b * stride + idx];
+        g = first ? t : g + t;
+        first = 0;
+    }
+    return g;
 }
 
 int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint8_t *action,
@@ -316,11 +343,7 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
         free(rec); free(items); free(phi_s); free(phi_n);
     }
     int total = 0;
-    for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
-        float s = nblk > 0 ? P[i] : 0.0f;
-        for (int b = 1; b < nblk; ++b) s = s + P[(size_t)b * NACT * NF + i];
-        G[i] = s;
-    }
+    for (size_t i = 0; i < (size_t)NACT * NF; ++i) G[i] = seg_sum(P, (size_t)NACT * NF, i, nblk);
     for (int b = 0; b < nblk; ++b) total += cnts[b];
     free(P); free(cnts);
     return total;
@@ -442,11 +465,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         free(phi_s); free(phi_n); free(items);
     }
     for (int k = 0; k < n_vf; ++k) {
-        for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
-            float s = nblk > 0 ? P[(size_t)k * NACT * NF + i] : 0.0f;
-            for (int b = 1; b < nblk; ++b) s = s + P[((size_t)b * n_vf + k) * NACT * NF + i];
-            G[(size_t)k * NACT * NF + i] = s;
-        }
+        for (size_t i = 0; i < (size_t)NACT * NF; ++i)
+            G[(size_t)k * NACT * NF + i] = seg_sum(P, (size_t)n_vf * NACT * NF, (size_t)k * NACT * NF + i, nblk);
         int tot = 0;
         for (int b = 0; b < nblk; ++b) tot += cnts[(size_t)b * n_vf + k];
         n_k[k] = tot;

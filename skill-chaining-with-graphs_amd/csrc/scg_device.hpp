@@ -91,6 +91,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// the same butterfly for N independent values, stage by stage (N independent chains hide the DPP hazards)
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0xB1, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0x4E, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0x141, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0x140, 0xF, 0xF, true));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+
 // ------------------------------------------------------------------ SPEC §1.3
 struct MapScalars {
     float hstep, R2, TX, TY, TR2, reach2;
@@ -128,32 +151,43 @@ __device__ __forceinline__ float pinball_step(const float *edges, const MapScala
                                               float &vx, float &vy, int a, bool &goal_out) {
     const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
     const float4 *E4 = reinterpret_cast<const float4 *>(edges);
-    // conservative candidate set: edges within 4.25 R of the start position (SPEC §1.3, last paragraph)
-    uint64_t cand[MAX_EDGES / 64];
-#pragma unroll
-    for (int g = 0; g < MAX_EDGES / 64; ++g) {
-        uint64_t m = 0;
-        if (g * 64 < ms.n_edges) {
-            const int jn = min(64, ms.n_edges - g * 64);
-            for (int j = 0; j < jn; ++j) {
-                const float4 ea = E4[2 * (g * 64 + j)];
-                const float inv = edges[8 * (g * 64 + j) + 4];
-                if (edge_d2(ea, inv, x, y) <= ms.reach2) m |= (1ull << j);
-            }
-        }
-        cand[g] = m;
-    }
+    // impulse + clip first: the speed |v| is now fixed for the whole step (mirror / reversal keep it)
     if (a == 0) vx = vx + DV;
     else if (a == 2) vx = vx - DV;
     else if (a == 1) vy = vy + DV;
     else if (a == 3) vy = vy - DV;
     vx = fminf(fmaxf(vx, -VMAX), VMAX);
     vy = fminf(fmaxf(vy, -VMAX), VMAX);
+    // Conservative candidate set (SPEC §1.3, last paragraph): the ball travels at most 21 |v| R/20 this step,
+    // so only edges within R (1 + 1.05 |v|) of the start position can be intercepted. The bound need not be
+    // exact, only safe: 1.10 instead of 1.05 and +2 % on the radius swallow the approximate sqrt and rounding.
+    const float spd = __builtin_sqrtf(fmaf(vy, vy, vx * vx));
+    const float rr = fmaf(1.10f, spd, 1.02f);
+    const float reach2 = ms.R2 * rr * rr;
+    uint64_t cand[MAX_EDGES / 64];
+    bool any = false;
+#pragma unroll
+    for (int g = 0; g < MAX_EDGES / 64; ++g) {
+        uint64_t m = 0;
+        if (g * 64 < ms.n_edges) {
+            const int jn = min(64, ms.n_edges - g * 64);
+#pragma unroll 4
+            for (int j = 0; j < jn; ++j) {
+                const float4 ea = E4[2 * (g * 64 + j)];
+                const float inv = edges[8 * (g * 64 + j) + 4];
+                if (edge_d2(ea, inv, x, y) <= reach2) m |= (1ull << j);
+            }
+        }
+        cand[g] = m;
+        any = any || (m != 0);
+    }
     bool goal = false;
     const float h = ms.hstep;
+    const bool wave_any = __ballot(any) != 0;             // wave-uniform: nobody near an edge -> free flight
     for (int i = 0; i < 20; ++i) {
         x = fmaf(vx, h, x); y = fmaf(vy, h, y);
         int nhit = 0, first = -1;
+        if (wave_any)
 #pragma unroll
         for (int g = 0; g < MAX_EDGES / 64; ++g) {
             uint64_t m = cand[g];

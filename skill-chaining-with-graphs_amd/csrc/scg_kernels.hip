@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 using namespace scg;
@@ -27,15 +28,19 @@ constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][256
 constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [256]
 constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [256] (+pad)
 constexpr int OFF_POW = OFF_INT + 4 * BLOCK_ENVS;              // float2 pow[256][2][20]
-constexpr int OFF_AB = OFF_POW + BLOCK_ENVS * 2 * 20 * 8;      // float2 ab[8][36]
-constexpr int OFF_BUF = OFF_AB + WAVES * 36 * 8;               // float buf[5*1296]
-constexpr int OFF_LIST = OFF_BUF + NACT * NF * 4;              // uint16 list[256]
-constexpr int OFF_DELTA = OFF_LIST + BLOCK_ENVS * 2;           // float delta[256] (per item)
-constexpr int OFF_MAXQ = OFF_DELTA + BLOCK_ENVS * 4;           // float maxq[256] (per item)
-constexpr int OFF_MISC = OFF_MAXQ + BLOCK_ENVS * 4;            // int misc[16]
-constexpr int LDS_BYTES = OFF_MISC + 64;
+constexpr int TAB_FLOATS = 72 * 8;                             // one table buffer: 72 entries x {x[4], y[4]}
+constexpr int SCR_BYTES = WAVES * 2 * TAB_FLOATS * 4;          // per wave two table buffers (36 KB)
+constexpr int POW_N = 21;                                      // Z_d^1..5 for d = 0..3, then (1,0)
+constexpr int OFF_BUF = OFF_POW + BLOCK_ENVS * 2 * POW_N * 8;  // float buf[5*1296] ALIASES the table scratch
+constexpr int BUF_BYTES = SCR_BYTES > NACT * NF * 4 ? SCR_BYTES : NACT * NF * 4;
+constexpr int OFF_ELIST = OFF_BUF + BUF_BYTES;                 // uint16 eval list[256]
+constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[256] (5 action runs)
+constexpr int OFF_DELTA = OFF_ULIST + BLOCK_ENVS * 2;          // float delta[256] (per env)
+constexpr int OFF_MAXQ = OFF_DELTA + BLOCK_ENVS * 4;           // float maxq[256] (per env)
+constexpr int OFF_MISC = OFF_MAXQ + BLOCK_ENVS * 4;            // int misc[32]
+constexpr int LDS_BYTES = OFF_MISC + 128;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(OFF_POW % 16 == 0 && OFF_AB % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
+static_assert(OFF_POW % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
@@ -56,7 +61,7 @@ struct StepArgs {
     float *slabs;                  // [nblk][n_vf][5][1296]
     int32_t *cnts;                 // [nblk][n_vf]
     int32_t n, n_vf, k_lo, k_hi;
-    uint32_t enabled, learn;
+    uint32_t enabled, learn, diag;
     uint64_t t, seed;
     int64_t env_base;
     float gamma, epsilon, r_succ;
@@ -76,6 +81,8 @@ __device__ __forceinline__ bool in_set(const StepArgs &A, int k, float x, float 
     return clf_z(A.clf + CLF_STRIDE * k, x, y) > 0.0f;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,9 +93,10 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     uint8_t *s_a = reinterpret_cast<uint8_t *>(smem + OFF_INT);
     uint8_t *s_ot = s_a + BLOCK_ENVS, *s_on = s_ot + BLOCK_ENVS;
     float2 *s_pow = reinterpret_cast<float2 *>(smem + OFF_POW);
-    float2 *s_ab = reinterpret_cast<float2 *>(smem + OFF_AB);
+    float *s_scr = reinterpret_cast<float *>(smem + OFF_BUF);          // table scratch, aliases s_buf
     float *s_buf = reinterpret_cast<float *>(smem + OFF_BUF);
-    uint16_t *s_list = reinterpret_cast<uint16_t *>(smem + OFF_LIST);
+    uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
+    uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
     float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
     float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
@@ -104,9 +112,10 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         __syncthreads();
     }
 
+    if (MODE == MODE_FUSED && A.diag == 1) return;
     // ------------------------------------------------------------------ phase P
-    if (tid < BLOCK_ENVS) {
-        const int i = tid, e = e0 + i;
+    if (lane < 32) {                                  // 8 waves x 32 lanes: two waves per SIMD hide LDS latency
+        const int i = wave * 32 + lane, e = e0 + i;
         if (i < nb) {
             if (MODE == MODE_FUSED) {
                 // act (SPEC §2, §4.3)
@@ -127,9 +136,11 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 float sx = A.x[e], sy = A.y[e], svx = A.vx[e], svy = A.vy[e];
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
+                if (A.diag == 3) { A.action[e] = (uint8_t)a; return; }
                 // physics (SPEC §1.3)
                 bool goal;
                 const float rew = pinball_step(s_edges, A.ms, sx, sy, svx, svy, a, goal);
+                if (A.diag == 4) { A.reward[e] = rew + sx + sy + svx + svy; return; }
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = A.ep_steps[e] + 1;
                 const bool timeout = !goal && eps1 >= A.max_ep;
@@ -192,244 +203,344 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     }
     __syncthreads();
 
+    if (MODE == MODE_FUSED && A.diag >= 2) return;
     // ------------------------------------------------------------------ phase Z (SPEC §3)
     {
         const int i = tid & (BLOCK_ENVS - 1), sg = tid >> 8;
         if (i < nb && (MODE != MODE_QVAL || sg == 1)) {
             const float *st = s_s + sg * 4 * BLOCK_ENVS;
             state_powers(st[i], st[BLOCK_ENVS + i], st[2 * BLOCK_ENVS + i], st[3 * BLOCK_ENVS + i],
-                         s_pow + (i * 2 + sg) * 20);
+                         s_pow + (i * 2 + sg) * POW_N);
+            s_pow[(i * 2 + sg) * POW_N + 20] = make_float2(1.0f, 0.0f);     // Z^0, so k = 0 needs no select
         }
     }
 
-    // lane-constant feature coordinates (SPEC §3.1)
+    // ------------------------------------------------------------------ phase TD (SPEC §5)
+    // One lane per 21 features; each wave handles GI = 4 items per iteration so that table building,
+    // LDS reads, control flow and the butterflies are amortised over four items, and the FMAs run as
+    // packed-fp32 over item pairs. Canonical orders are untouched: item -> wave by list position mod 8,
+    // every dot product is one fma chain over slots 0..20 per lane, items accumulate in list order.
+    constexpr int GI = 4;
     const int hi = lane >> 5, col = lane & 31;
-    const int c3m = col / 6, c4m = col - 6 * c3m;        // main column c34 = col
-    const int c4t = 2 + (lane & 3);                       // tail column c34 = 32 + (lane&3): c3 = 5
-    const int c1p = lane / 6, c2p = lane - 6 * c1p;       // AB product owned by lanes 0..35
     const int tl = lane >> 2;                             // tail row part: c12 = 16 t + tl
     const bool v20 = lane < 16;                           // slot 20 holds a feature only in lanes 0..15
+    const float m20 = v20 ? 1.0f : 0.0f;
 
-    // Per-lane base pointers; every access below is base[compile-time constant], so the address is one
-    // VGPR + an immediate (hipcc otherwise materialises ~100 separate addresses and spills them).
-    float2 *abw = s_ab + wave * 36;                       // this wave's AB table of the item in flight
-    const float2 *ab_m = abw + hi;                        // main slots:  ab_m[2j]
-    const float2 *ab_t = abw + tl;                        // tail slots 18,19: ab_t[16t]
-    const float2 *ab_t2 = abw + min(32 + tl, 35);         // tail slot 20 (clamped; masked by v20)
+    // scratch tables: per wave 2 buffers x 72 entries (AB 0..35, CD 36..71) x {x[4 items], y[4 items]}
+    float *scr0 = s_scr + wave * (2 * TAB_FLOATS);
+    const float4 *t_m0 = reinterpret_cast<const float4 *>(scr0) + 2 * hi;                    // [4j], [4j+1]
+    const float4 *t_t0 = reinterpret_cast<const float4 *>(scr0) + 2 * tl;                    // [32t], [32t+1]
+    const float4 *t_t20 = reinterpret_cast<const float4 *>(scr0) + 2 * min(32 + tl, 35);
+    const float4 *t_cm0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + col);
+    const float4 *t_ct0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + 32 + (lane & 3));
     float *buf_m = s_buf + hi * 36 + col;                 // buf_m[a*NF + 72j]
     float *buf_t = s_buf + tl * 36 + 32 + (lane & 3);     // buf_t[a*NF + 576t]
-    const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets, same split
-    const uint32_t w_vt = (uint32_t)(tl * 36 + 32 + (lane & 3)) * 4u;
 
-    // R = W_k in loops A and B, the gradient accumulator in loop C: the two are never live together
-    // (held together, 2 x 105 VGPRs + working set spilled ~80 registers inside the item loop).
-    float R[NACT][NSLOT];
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(A.W), 0, (MODE == MODE_QVAL ? 1 : A.n_vf) * NACT * NF * 4, 0x00020000);
-
-// all 21 AB factors of the item in flight -> registers, in one burst of LDS reads
-#define SCG_LOAD_AB(ABV)                                                  \
-    float2 ABV[NSLOT];                                                    \
-    _Pragma("unroll") for (int j_ = 0; j_ < 18; ++j_) ABV[j_] = ab_m[2 * j_]; \
-    ABV[18] = ab_t[0]; ABV[19] = ab_t[16]; ABV[20] = ab_t2[0];
-// phi of slot J from the prefetched AB factors and the lane's two column factors cdm / cdt
-#define SCG_PHI(J, ABV, PH)                                               \
-    float PH;                                                             \
-    {                                                                     \
-        const float2 cd_ = (J) < 18 ? cdm : cdt;                          \
-        PH = fmaf(-ABV[J].y, cd_.y, ABV[J].x * cd_.x);                    \
-        if ((J) == 20) PH = v20 ? PH : 0.0f;                              \
+    // table building: lane l owns entry l (round 0) and, for l < 8, entry 64 + l (round 1) of all 4 items.
+    // Entry e < 36: AB = Z_0^(e/6) * Z_1^(e%6); e >= 36: CD = Z_2^(q/6) * Z_3^(q%6), q = e - 36. Offsets into
+    // a state's 21-entry power table (entry 20 = Z^0), in float2 units.
+    auto pow_off = [](int d, int kk) { return kk > 0 ? d * 5 + kk - 1 : 20; };
+    int goa[2], gob[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = 64 * r + lane;
+        const int qd = e < 36 ? e : e - 36, d0 = e < 36 ? 0 : 2;
+        const int ka = (qd / 6) % 6, kb = qd % 6;
+        goa[r] = pow_off(d0, ka); gob[r] = pow_off(d0 + 1, kb);
     }
+    auto gen_tables = [&](const int (&ie)[GI], int sg, float *dst) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r == 0 || lane < 8) {
+                float zx[GI], zy[GI];
+#pragma unroll
+                for (int g = 0; g < GI; ++g) {
+                    const float2 *pw = s_pow + (ie[g] * 2 + sg) * POW_N;
+                    const float2 z = cmul(pw[goa[r]], pw[gob[r]]);
+                    zx[g] = z.x; zy[g] = z.y;
+                }
+                float4 *d4 = reinterpret_cast<float4 *>(dst) + 2 * (64 * r + lane);
+                d4[0] = make_float4(zx[0], zx[1], zx[2], zx[3]);
+                d4[1] = make_float4(zy[0], zy[1], zy[2], zy[3]);
+            }
+        }
+    };
+    // quad descriptor: list entries [i0, i0 + 4) (block-local env indices); a missing entry repeats the first
+    auto load_group = [&](const uint16_t *lst, int cnt, int i0, int (&ie)[GI], bool (&ok)[GI]) {
+#pragma unroll
+        for (int g = 0; g < GI; ++g) {
+            ok[g] = i0 + g < cnt;
+            ie[g] = __builtin_amdgcn_readfirstlane((int)lst[ok[g] ? i0 + g : i0]);
+        }
+    };
 
-    // ------------------------------------------------------------------ phase TD, VF by VF (SPEC §5)
+    // R = W_k in loops A and B, the gradient accumulator in loop C: never live together. Stored as action
+    // pairs (a0,a1), (a2,a3) + a4 so that loop A's packed FMAs take real register pairs: a {w,w} splat
+    // operand costs a second VGPR per weight once hipcc hoists it out of the group loop (it did: 2 x 105).
+    v2f Rp[2][NSLOT];
+    float R4[NSLOT];
+#define SCG_R(AA, J) ((AA) == 0 ? Rp[0][J].x : (AA) == 1 ? Rp[0][J].y : (AA) == 2 ? Rp[1][J].x : (AA) == 3 ? Rp[1][J].y : R4[J])
+#define SCG_R_SET(AA, J, V)                                                                     \
+    do {                                                                                        \
+        if ((AA) == 0) Rp[0][J].x = (V); else if ((AA) == 1) Rp[0][J].y = (V);                  \
+        else if ((AA) == 2) Rp[1][J].x = (V); else if ((AA) == 3) Rp[1][J].y = (V); else R4[J] = (V); \
+    } while (0)
+
+// table reads of slot J (compile-time J): x[4] / y[4] of the slot's AB entry
+#define SCG_LDX(J) ((J) < 18 ? t_m[4 * (J)] : ((J) < 20 ? t_t[32 * ((J)-18)] : t_t2[0]))
+#define SCG_LDY(J) ((J) < 18 ? t_m[4 * (J) + 1] : ((J) < 20 ? t_t[32 * ((J)-18) + 1] : t_t2[1]))
+// The slot loop shared by loops A, B and C: for j = 0..20 form phi of the group's 4 items (pa = items 0,1;
+// pb = items 2,3; packed fp32) from the tables at T_M/T_T/T_T2 and the lane's column factors, then run BODY.
+// Table reads are register-pipelined two slots ahead and sched_barrier pins that pattern (left alone,
+// hipcc hoists all 42 ds_read_b128 of a group and spills hundreds of VGPRs).
+#define SCG_SLOT_LOOP(...)                                                                              \
+    {                                                                                                   \
+        float4 ax0 = SCG_LDX(0), ay0 = SCG_LDY(0);                                                      \
+        _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                                             \
+            float4 ax1 = ax0, ay1 = ay0;                                                                \
+            if (j + 1 < NSLOT) { ax1 = SCG_LDX(j + 1); ay1 = SCG_LDY(j + 1); }                          \
+            if (j == 18) { ccx = t_ct0[boff]; ccy = t_ct0[boff + 1]; }   /* tail column factor from here on */ \
+            const float4 cx_ = ccx, cy_ = ccy;                                                          \
+            const v2f ax01 = {ax0.x, ax0.y}, ax23 = {ax0.z, ax0.w}, ay01 = {ay0.x, ay0.y}, ay23 = {ay0.z, ay0.w}; \
+            const v2f cx01 = {cx_.x, cx_.y}, cx23 = {cx_.z, cx_.w}, cy01 = {cy_.x, cy_.y}, cy23 = {cy_.z, cy_.w}; \
+            v2f pa = __builtin_elementwise_fma(-ay01, cy01, ax01 * cx01);                               \
+            v2f pb = __builtin_elementwise_fma(-ay23, cy23, ax23 * cx23);                               \
+            if (j == 20) { pa = pa * (v2f){m20, m20}; pb = pb * (v2f){m20, m20}; }                      \
+            { __VA_ARGS__ }                                                                             \
+            ax0 = ax1; ay0 = ay1;                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+        }                                                                                               \
+    }
+// quad prologue: wait for this quad's tables, start the next quad's (index QN, if < NQ), bind table pointers
+#define SCG_GROUP_BEGIN(LST, CNT, QN, NQ, SG)                                                           \
+    const int boff = (par & 1) * (TAB_FLOATS / 4);                                                      \
+    int ne[GI];                                                                                         \
+    bool nok[GI];                                                                                       \
+    wave_lds_sync();                                                                                    \
+    load_group(LST, CNT, 4 * ((QN) < (NQ) ? (QN) : qi), ne, nok);                                       \
+    if ((QN) < (NQ)) gen_tables(ne, SG, scr0 + TAB_FLOATS - boff * 4);                                  \
+    const float4 *t_m = t_m0 + boff, *t_t = t_t0 + boff, *t_t2 = t_t20 + boff;                          \
+    float4 ccx = t_cm0[boff], ccy = t_cm0[boff + 1];          /* the lane's main column factor (slots 0..17) */
+#define SCG_GROUP_END                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < GI; ++g) { ie[g] = ne[g]; ok[g] = nok[g]; }                   \
+    ++par;
+
     for (int k = A.k_lo; k <= A.k_hi; ++k) {
         __syncthreads();
-        bool has = false, upd = false;
+        // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 256 envs:
+        //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), env order
+        //   update lists: envs that update VF k, one run per action a_t, env order inside a run
+        // Quads of 4 consecutive list entries are dealt to the waves round-robin (quad q -> wave q mod 8);
+        // an update quad never straddles two actions, so the inner loops are specialised per action and
+        // every accumulator row acc[a] sees exactly its own items.
+        bool ev = false, up = false;
+        int at = -1;
         if (tid < nb) {
             const int ot = s_ot[tid], on = s_on[tid];
-            upd = (MODE != MODE_QVAL) && A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
-            has = upd || (on == k);
+            up = (MODE != MODE_QVAL) && A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
+            const float cont = (k == 0) ? s_c0[tid] : s_co[tid];
+            ev = (on == k) || (up && cont > 0.0f);
+            at = s_a[tid];
         }
-        uint64_t mh = 0;
+        uint64_t mb[1 + NACT];
         if (wave < 4) {
-            mh = __ballot(has);
-            const uint64_t mu = __ballot(upd);
-            if (lane == 0) { s_misc[wave] = __popcll(mh); s_misc[4 + wave] = __popcll(mu); }
+            mb[0] = __ballot(ev);
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) mb[1 + a] = __ballot(up && at == a);
+            if (lane < 1 + NACT) {
+                const uint64_t mine = lane == 0 ? mb[0] : lane == 1 ? mb[1] : lane == 2 ? mb[2] : lane == 3 ? mb[3]
+                                                        : lane == 4 ? mb[4] : mb[5];
+                s_misc[wave * 8 + lane] = __popcll(mine);
+            }
         }
         __syncthreads();
-        if (wave < 4 && has) {
-            int off = 0;
-            for (int w2 = 0; w2 < wave; ++w2) off += s_misc[w2];
-            s_list[off + __popcll(mh & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+        int n_ev = 0, run_len[NACT], run_off[NACT], qbase[NACT + 1];
+        {
+            n_ev = __builtin_amdgcn_readfirstlane(s_misc[0] + s_misc[8] + s_misc[16] + s_misc[24]);
+            int off = 0, qb = 0;
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {      // wave-uniform: keep them in SGPRs (16 VGPRs otherwise)
+                run_len[a] = __builtin_amdgcn_readfirstlane(s_misc[1 + a] + s_misc[9 + a] + s_misc[17 + a] + s_misc[25 + a]);
+                run_off[a] = off; qbase[a] = qb;
+                off += run_len[a]; qb += (run_len[a] + 3) >> 2;
+            }
+            qbase[NACT] = qb;
         }
-        const int m = s_misc[0] + s_misc[1] + s_misc[2] + s_misc[3];
-        const int nupd = s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
+        const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
+        if (wave < 4) {
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (ev) {
+                int off = 0;
+                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[w2 * 8];
+                s_elist[off + __popcll(mb[0] & below)] = (uint16_t)tid;
+            }
+            if (up) {
+                int off = 0;
+                const uint64_t mine = at == 0 ? mb[1] : at == 1 ? mb[2] : at == 2 ? mb[3] : at == 3 ? mb[4] : mb[5];
+                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[w2 * 8 + 1 + at];
+                const int ro = at == 0 ? run_off[0] : at == 1 ? run_off[1] : at == 2 ? run_off[2] : at == 3 ? run_off[3] : run_off[4];
+                s_ulist[ro + off + __popcll(mine & below)] = (uint16_t)tid;
+            }
+        }
         __syncthreads();
         if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = nupd;
-        if (m == 0) continue;
+        if (n_ev + nupd == 0) continue;
 
-        // W_k -> registers: one descriptor, lane offset in a VGPR, everything else in the scalar offset
+        // W_k -> LDS once per workgroup (coalesced float4; the staging area is the reduction buffer, idle
+        // here) -> each lane's 105 weights -> registers. Eight waves no longer fetch the same 26 KB each.
         {
-            const uint32_t kbase = (MODE == MODE_QVAL) ? 0u : (uint32_t)k * (NACT * NF * 4);
+            const float4 *Wk4 = reinterpret_cast<const float4 *>(A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF));
+            float4 *b4 = reinterpret_cast<float4 *>(s_buf);
+            for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) b4[f4] = Wk4[f4];
+            __syncthreads();
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-                for (int j = 0; j < 18; ++j)
-                    R[a][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        w_rsrc, w_vm, kbase + (uint32_t)(a * NF + 72 * j) * 4u, 0));
+                for (int j = 0; j < 18; ++j) SCG_R_SET(a, j, buf_m[a * NF + 72 * j]);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        w_rsrc, (t < 2 || v20) ? w_vt : 0u, kbase + (uint32_t)(a * NF + 576 * t) * 4u, 0));
-                    R[a][18 + t] = (t < 2 || v20) ? v : 0.0f;
+                    const float v = buf_t[a * NF + 576 * t];       // lanes >= 16 read a neighbour's weight at t = 2
+                    SCG_R_SET(a, 18 + t, (t < 2 || v20) ? v : 0.0f);
                 }
             }
+            __syncthreads();                                       // the staging area becomes table scratch
         }
 
-        // wave-uniform item predicates (LDS broadcast reads, forced into SGPRs)
-        auto item_env = [&](int it) { return __builtin_amdgcn_readfirstlane((int)s_list[it]); };
-        auto is_upd = [&](int i) {
-            return (MODE != MODE_QVAL) && A.learn &&
-                   ((MODE == MODE_FUSED && k == 0) || __builtin_amdgcn_readfirstlane((int)s_ot[i]) == k);
-        };
-        auto item_cont = [&](int i) {
-            return __builtin_amdgcn_readfirstlane(__float_as_int((k == 0) ? s_c0[i] : s_co[i]));
-        };
-        auto wants_eval = [&](int it) {
-            const int i = item_env(it);
-            const bool cache = __builtin_amdgcn_readfirstlane((int)s_on[i]) == k;
-            return cache || (is_upd(i) && __int_as_float(item_cont(i)) > 0.0f);
-        };
-        auto wants_upd = [&](int it) { return is_upd(item_env(it)); };
-        // AB table of (env i, state sg) -> this wave's LDS scratch (lanes 0..35, one product each)
-        auto gen_ab = [&](int i, int sg) {
-            const float2 *pw = s_pow + (i * 2 + sg) * 20;
-            if (lane < 36) abw[lane] = cmul(pow_at(pw, 0, c1p), pow_at(pw, 1, c2p));
-        };
-
-        // ---- loop A (W_k live): Q_k(s_next, .) -> qcache, max -> s_maxq[item].
-        // Software-pipelined: the next item's AB table is written to LDS while this item's FMAs run.
+        // ---- loop A (W_k live): Q_k(s_next, .) of one quad at a time -> qcache, max -> s_maxq[env]
         {
-            int it = wave;
-            while (it < m && !wants_eval(it)) it += WAVES;
-            if (it < m) gen_ab(item_env(it), 1);
-            while (it < m) {
-                const int i = item_env(it);
-                const float2 *pw = s_pow + (i * 2 + 1) * 20;
-                wave_lds_sync();
-                SCG_LOAD_AB(abv)
-                const float2 cdm = cmul(pow_at(pw, 2, c3m), pow_at(pw, 3, c4m));
-                const float2 cdt = cmul(pow_at(pw, 2, 5), pow_at(pw, 3, c4t));
-                int nx = it + WAVES;
-                while (nx < m && !wants_eval(nx)) nx += WAVES;
-                wave_lds_sync();
-                if (nx < m) gen_ab(item_env(nx), 1);
-                float q[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            const int nq = (n_ev + 3) >> 2;
+            if (wave < nq) {
+                int ie[GI], par = 0;
+                bool ok[GI];
+                load_group(s_elist, n_ev, 4 * wave, ie, ok);
+                gen_tables(ie, 1, scr0);
+                for (int qi = wave; qi < nq; qi += WAVES) {
+                    SCG_GROUP_BEGIN(s_elist, n_ev, qi + WAVES, nq, 1)
+                    v2f q01[GI], q23[GI];
+                    float q4[GI];
 #pragma unroll
-                for (int j = 0; j < NSLOT; ++j) {
-                    SCG_PHI(j, abv, ph)
+                    for (int g = 0; g < GI; ++g) { q01[g] = (v2f){0.0f, 0.0f}; q23[g] = (v2f){0.0f, 0.0f}; q4[g] = 0.0f; }
+                    SCG_SLOT_LOOP(
+                        const float ph[GI] = {pa.x, pa.y, pb.x, pb.y};
+                        _Pragma("unroll") for (int g = 0; g < GI; ++g) {
+                            const v2f p2 = {ph[g], ph[g]};                            // op_sel splat of a pair half
+                            q01[g] = __builtin_elementwise_fma(Rp[0][j], p2, q01[g]);
+                            q23[g] = __builtin_elementwise_fma(Rp[1][j], p2, q23[g]);
+                            q4[g] = fmaf(R4[j], ph[g], q4[g]);
+                        })
+                    float qv[GI * NACT];
 #pragma unroll
-                    for (int a = 0; a < NACT; ++a) q[a] = fmaf(R[a][j], ph, q[a]);
+                    for (int g = 0; g < GI; ++g) {
+                        qv[g * NACT + 0] = q01[g].x; qv[g * NACT + 1] = q01[g].y;
+                        qv[g * NACT + 2] = q23[g].x; qv[g * NACT + 3] = q23[g].y; qv[g * NACT + 4] = q4[g];
+                    }
+                    wave_sum_n<GI * NACT>(qv);
+                    // qcache[a][env] from lanes 0..19 (lane = 5 g + a)
+                    {
+                        float myv = 0.0f;
+#pragma unroll
+                        for (int idx = 0; idx < GI * NACT; ++idx) myv = (lane == idx) ? qv[idx] : myv;
+                        const int gl = lane / NACT, al = lane - NACT * gl;
+                        const int il = gl == 0 ? ie[0] : gl == 1 ? ie[1] : gl == 2 ? ie[2] : ie[3];
+                        const bool okl = gl == 0 ? ok[0] : gl == 1 ? ok[1] : gl == 2 ? ok[2] : (gl == 3 && ok[3]);
+                        if (lane < GI * NACT && okl && s_on[il] == k) A.qcache[(size_t)al * N + e0 + il] = myv;
+                    }
+#pragma unroll
+                    for (int g = 0; g < GI; ++g) {
+                        float mx = qv[g * NACT];
+#pragma unroll
+                        for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qv[g * NACT + a]);
+                        if (ok[g] && lane == 0) s_maxq[ie[g]] = mx;
+                    }
+                    SCG_GROUP_END
                 }
-#pragma unroll
-                for (int a = 0; a < NACT; ++a) q[a] = wave_sum(q[a]);
-                const bool cache = __builtin_amdgcn_readfirstlane((int)s_on[i]) == k;
-                if (cache && lane < NACT) {
-                    const float v = lane == 0 ? q[0] : lane == 1 ? q[1] : lane == 2 ? q[2] : lane == 3 ? q[3] : q[4];
-                    A.qcache[(size_t)lane * N + e0 + i] = v;
-                }
-                float mx = q[0];
-#pragma unroll
-                for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, q[a]);
-                if (lane == 0) s_maxq[it] = mx;          // read back by this same wave in loop B
-                it = nx;
             }
         }
         if (MODE == MODE_QVAL || nupd == 0) continue;
+        __syncthreads();                                   // s_maxq crosses waves (loop B deals quads differently)
 
-        // ---- loop B (W_k live): Q_k(s, a_t), TD error -> s_delta[item]
-        {
-            int it = wave;
-            while (it < m && !wants_upd(it)) it += WAVES;
-            if (it < m) gen_ab(item_env(it), 0);
-            while (it < m) {
-                const int i = item_env(it);
-                const float2 *pw = s_pow + (i * 2 + 0) * 20;
-                wave_lds_sync();
-                SCG_LOAD_AB(abv)
-                const float2 cdm = cmul(pow_at(pw, 2, c3m), pow_at(pw, 3, c4m));
-                const float2 cdt = cmul(pow_at(pw, 2, 5), pow_at(pw, 3, c4t));
-                int nx = it + WAVES;
-                while (nx < m && !wants_upd(nx)) nx += WAVES;
-                wave_lds_sync();
-                if (nx < m) gen_ab(item_env(nx), 0);
-                const int at = __builtin_amdgcn_readfirstlane((int)s_a[i]);
-                float qsa = 0.0f;
-#define SCG_QSA_CASE(AA)                                                   \
-    case AA:                                                               \
-        _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
-            SCG_PHI(j, abv, ph)                                            \
-            qsa = fmaf(R[AA][j], ph, qsa);                                 \
-        }                                                                  \
-        break;
-                switch (at) { SCG_QSA_CASE(0) SCG_QSA_CASE(1) SCG_QSA_CASE(2) SCG_QSA_CASE(3) default:
-                    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
-                        SCG_PHI(j, abv, ph)
-                        qsa = fmaf(R[4][j], ph, qsa);
+        // ---- loop B (W_k live): Q_k(s, a_t) -> TD error -> s_delta[env], one action run at a time
+        auto loop_b = [&](auto aa_c) {
+            constexpr int AA = decltype(aa_c)::value;
+            const int cnt = run_len[AA], nq = (cnt + 3) >> 2;
+            const uint16_t *lst = s_ulist + run_off[AA];
+            const int q0 = (wave - qbase[AA]) & (WAVES - 1);          // first quad of this run dealt to this wave
+            if (q0 >= nq) return;
+            int ie[GI], par = 0;
+            bool ok[GI];
+            wave_lds_sync();
+            load_group(lst, cnt, 4 * q0, ie, ok);
+            gen_tables(ie, 0, scr0);
+            for (int qi = q0; qi < nq; qi += WAVES) {
+                SCG_GROUP_BEGIN(lst, cnt, qi + WAVES, nq, 0)
+                v2f qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
+                SCG_SLOT_LOOP(
+                    if constexpr (AA < 4) {
+                        const v2f w2 = {SCG_R(AA, j), SCG_R(AA, j)};                  // op_sel splat of a pair half
+                        qa = __builtin_elementwise_fma(w2, pa, qa);
+                        qb = __builtin_elementwise_fma(w2, pb, qb);
+                    } else {
+                        qa.x = fmaf(R4[j], pa.x, qa.x); qa.y = fmaf(R4[j], pa.y, qa.y);
+                        qb.x = fmaf(R4[j], pb.x, qb.x); qb.y = fmaf(R4[j], pb.y, qb.y);
+                    })
+                float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
+                wave_sum_n<GI>(qs);
+#pragma unroll
+                for (int g = 0; g < GI; ++g) {
+                    if (ok[g]) {
+                        const int i = ie[g];
+                        const float r = (k == 0) ? s_r0[i] : s_ro[i];
+                        const float cont = (k == 0) ? s_c0[i] : s_co[i];
+                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[i], r) : r;
+                        if (lane == 0) s_delta[i] = target - qs[g];    // read back by this same wave in loop C
                     }
-                    break; }
-#undef SCG_QSA_CASE
-                qsa = wave_sum(qsa);
-                const float r = (k == 0) ? s_r0[i] : s_ro[i];
-                const float cont = __int_as_float(item_cont(i));
-                const float target = cont > 0.0f ? fmaf(cont, s_maxq[it], r) : r;
-                if (lane == 0) s_delta[it] = target - qsa;     // read back by this same wave in loop C
-                it = nx;
+                }
+                SCG_GROUP_END
             }
-        }
+        };
+        loop_b(std::integral_constant<int, 0>{}); loop_b(std::integral_constant<int, 1>{});
+        loop_b(std::integral_constant<int, 2>{}); loop_b(std::integral_constant<int, 3>{});
+        loop_b(std::integral_constant<int, 4>{});
 
-        // ---- loop C (accumulator live): acc[a_t][f] = fma(delta, phi_f(s), acc[a_t][f])
+        // ---- loop C (accumulator live): acc[a][f] = fma(delta, phi_f(s), acc[a][f]), quads in order.
+        // A separate float array (W's register pairs are dead by now and get reused).
+        float Acc[NACT][NSLOT];
 #pragma unroll
         for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-            for (int j = 0; j < NSLOT; ++j) R[a][j] = 0.0f;
+            for (int j = 0; j < NSLOT; ++j) Acc[a][j] = 0.0f;
         }
-        {
-            int it = wave;
-            while (it < m && !wants_upd(it)) it += WAVES;
-            if (it < m) gen_ab(item_env(it), 0);
-            while (it < m) {
-                const int i = item_env(it);
-                const float2 *pw = s_pow + (i * 2 + 0) * 20;
-                wave_lds_sync();
-                SCG_LOAD_AB(abv)
-                const float2 cdm = cmul(pow_at(pw, 2, c3m), pow_at(pw, 3, c4m));
-                const float2 cdt = cmul(pow_at(pw, 2, 5), pow_at(pw, 3, c4t));
-                int nx = it + WAVES;
-                while (nx < m && !wants_upd(nx)) nx += WAVES;
-                wave_lds_sync();
-                if (nx < m) gen_ab(item_env(nx), 0);
-                const int at = __builtin_amdgcn_readfirstlane((int)s_a[i]);
-                const float delta = s_delta[it];
-#define SCG_UPD_CASE(AA)                                                   \
-    case AA:                                                               \
-        _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                \
-            SCG_PHI(j, abv, ph)                                            \
-            R[AA][j] = fmaf(delta, ph, R[AA][j]);                          \
-        }                                                                  \
-        break;
-                switch (at) { SCG_UPD_CASE(0) SCG_UPD_CASE(1) SCG_UPD_CASE(2) SCG_UPD_CASE(3) default:
-                    _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {
-                        SCG_PHI(j, abv, ph)
-                        R[4][j] = fmaf(delta, ph, R[4][j]);
-                    }
-                    break; }
-#undef SCG_UPD_CASE
-                it = nx;
+        auto loop_c = [&](auto aa_c) {
+            constexpr int AA = decltype(aa_c)::value;
+            const int cnt = run_len[AA], nq = (cnt + 3) >> 2;
+            const uint16_t *lst = s_ulist + run_off[AA];
+            const int q0 = (wave - qbase[AA]) & (WAVES - 1);
+            if (q0 >= nq) return;
+            int ie[GI], par = 0;
+            bool ok[GI];
+            wave_lds_sync();
+            load_group(lst, cnt, 4 * q0, ie, ok);
+            gen_tables(ie, 0, scr0);
+            for (int qi = q0; qi < nq; qi += WAVES) {
+                SCG_GROUP_BEGIN(lst, cnt, qi + WAVES, nq, 0)
+                float dl[GI];
+#pragma unroll
+                for (int g = 0; g < GI; ++g) dl[g] = ok[g] ? s_delta[ie[g]] : 0.0f;     // padding item: += 0
+                SCG_SLOT_LOOP(
+                    Acc[AA][j] = fmaf(dl[0], pa.x, Acc[AA][j]);
+                    Acc[AA][j] = fmaf(dl[1], pa.y, Acc[AA][j]);
+                    Acc[AA][j] = fmaf(dl[2], pb.x, Acc[AA][j]);
+                    Acc[AA][j] = fmaf(dl[3], pb.y, Acc[AA][j]);)
+                SCG_GROUP_END
             }
-        }
+        };
+        loop_c(std::integral_constant<int, 0>{}); loop_c(std::integral_constant<int, 1>{});
+        loop_c(std::integral_constant<int, 2>{}); loop_c(std::integral_constant<int, 3>{});
+        loop_c(std::integral_constant<int, 4>{});
 
-        // block partial: ((acc_0 + acc_1) + ...) + acc_7, through LDS in wave order
+        // block partial: ((acc_0 + acc_1) + ...) + acc_7, through LDS in wave order (the buffer aliases
+        // the table scratch, so every wave must be out of loop C first)
+        __syncthreads();
         for (int w = 0; w < WAVES; ++w) {
             if (wave == w) {
 #pragma unroll
@@ -437,13 +548,13 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 #pragma unroll
                     for (int j = 0; j < 18; ++j) {
                         float *p = &buf_m[a * NF + 72 * j];
-                        *p = (w == 0) ? R[a][j] : *p + R[a][j];
+                        *p = (w == 0) ? Acc[a][j] : *p + Acc[a][j];
                     }
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         if (t < 2 || v20) {
                             float *p = &buf_t[a * NF + 576 * t];
-                            *p = (w == 0) ? R[a][18 + t] : *p + R[a][18 + t];
+                            *p = (w == 0) ? Acc[a][18 + t] : *p + Acc[a][18 + t];
                         }
                     }
                 }
@@ -453,8 +564,13 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
         for (int f = tid; f < NACT * NF; f += THREADS) slab[f] = s_buf[f];
     }
-#undef SCG_PHI
-#undef SCG_LOAD_AB
+#undef SCG_LDX
+#undef SCG_LDY
+#undef SCG_SLOT_LOOP
+#undef SCG_GROUP_BEGIN
+#undef SCG_GROUP_END
+#undef SCG_R
+#undef SCG_R_SET
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,18 +582,56 @@ struct ReduceArgs {
     int32_t *n_k;
     float *W;
     const float *scale;
+    float *segs;             // [nseg][n_vf][5][1296] first-level partial sums
+    int32_t *segcnt;         // [nseg][n_vf]
     int32_t nblk, n_vf;
     float alpha;
     uint32_t apply;
 };
 
 constexpr int RED_THREADS = 64;
-__global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
+constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
+
+// level 1: T_s = ((P_16s + P_16s+1) + ...) over the segment's non-empty blocks, all 16 loads in flight.
+// grid (column chunks, segments, n_vf): 26 x nblk/16 x n_vf workgroups stream the slabs once.
+__global__ __launch_bounds__(RED_THREADS) void reduce1_kernel(const ReduceArgs R) {
+    const int k = blockIdx.z, sg = blockIdx.y, tid = threadIdx.x;
+    const int b0 = sg * SEG;
+    const int i4 = blockIdx.x * RED_THREADS + tid;
+    int tot = 0;
+    bool on[SEG];
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        const int b = b0 + u;
+        const int c = b < R.nblk ? R.cnts[(size_t)b * R.n_vf + k] : 0;     // wave-uniform
+        on[u] = c > 0;
+        tot += c;
+    }
+    if (blockIdx.x == 0 && tid == 0) R.segcnt[(size_t)sg * R.n_vf + k] = tot;
+    if (i4 >= NACT * NF / 4 || tot == 0) return;
+    const size_t stride4 = (size_t)R.n_vf * NACT * NF / 4;
+    const float4 *p = reinterpret_cast<const float4 *>(R.slabs) + (size_t)k * (NACT * NF / 4) + i4;
+    float4 v[SEG];
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (on[u]) v[u] = p[(size_t)(b0 + u) * stride4];
+    }
+    float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+        if (on[u]) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
+    }
+    reinterpret_cast<float4 *>(R.segs)[((size_t)sg * R.n_vf + k) * (NACT * NF / 4) + i4] = T;
+}
+
+// level 2: G = ((T_0 + T_1) + ...) over non-empty segments, n_k, optional apply (SPEC §5)
+__global__ __launch_bounds__(RED_THREADS) void reduce2_kernel(const ReduceArgs R) {
     __shared__ int s_cnt[RED_THREADS];
-    const int k = blockIdx.y;
-    const int tid = threadIdx.x;
+    const int k = blockIdx.y, tid = threadIdx.x;
+    const int nseg = (R.nblk + SEG - 1) / SEG;
     int c = 0;
-    for (int b = tid; b < R.nblk; b += RED_THREADS) c += R.cnts[(size_t)b * R.n_vf + k];
+    for (int sg = tid; sg < nseg; sg += RED_THREADS) c += R.segcnt[(size_t)sg * R.n_vf + k];
     s_cnt[tid] = c;
     __syncthreads();
     for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
@@ -486,27 +640,15 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     }
     const int nk = s_cnt[0];
     if (blockIdx.x == 0 && tid == 0) R.n_k[k] = nk;
-    // one float4 (4 consecutive weights) per thread; the sum over blocks stays strictly in block order
-    // (SPEC §5) but the loads of 16 slabs are in flight together — the kernel is a 26 KB x nblk x n_vf stream.
     const int i4 = blockIdx.x * RED_THREADS + tid;
     if (i4 >= NACT * NF / 4) return;
     float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 *p = reinterpret_cast<const float4 *>(R.segs) + (size_t)k * (NACT * NF / 4) + i4;
     const size_t stride4 = (size_t)R.n_vf * NACT * NF / 4;
-    const float4 *p = reinterpret_cast<const float4 *>(R.slabs) + (size_t)k * (NACT * NF / 4) + i4;
-    constexpr int U = 16;
-    for (int b0 = 0; b0 < R.nblk; b0 += U) {
-        float4 v[U];
-        bool on[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = b0 + u;
-            on[u] = b < R.nblk && R.cnts[(size_t)b * R.n_vf + k] > 0;     // wave-uniform
-            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (on[u]) v[u] = p[(size_t)b * stride4];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (on[u]) { S.x = S.x + v[u].x; S.y = S.y + v[u].y; S.z = S.z + v[u].z; S.w = S.w + v[u].w; }
+    for (int sg = 0; sg < nseg; ++sg) {
+        if (R.segcnt[(size_t)sg * R.n_vf + k] > 0) {
+            const float4 t = p[(size_t)sg * stride4];
+            S.x = S.x + t.x; S.y = S.y + t.y; S.z = S.z + t.z; S.w = S.w + t.w;
         }
     }
     reinterpret_cast<float4 *>(R.G)[(size_t)k * (NACT * NF / 4) + i4] = S;
@@ -632,6 +774,8 @@ struct scg_ctx {
     int32_t *d_cnts;
     float *d_G;
     int32_t *d_nk;
+    float *d_segs;
+    int32_t *d_segcnt;
     float *G_out;          // where reduce leaves G / n_k (ctx-owned by default)
     int32_t *nk_out;
     bool prof_on;          // measurement hook: event pairs round the fused kernel
@@ -699,6 +843,9 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_slabs, slab_bytes) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_cnts, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_G, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        const size_t nseg = (size_t)(c->nblk + SEG - 1) / SEG;
+        if (hipMalloc(&c->d_segs, nseg * c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_segcnt, nseg * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_nk, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_edges, MAX_EDGES * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
@@ -725,6 +872,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
 int scg_destroy(scg_ctx *c) {
     if (!c) return SCG_OK;
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
+    (void)hipFree(c->d_segs); (void)hipFree(c->d_segcnt);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
@@ -779,8 +927,14 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
     ReduceArgs R;
     R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
     R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
-    dim3 grid((NACT * NF / 4 + RED_THREADS - 1) / RED_THREADS, c->n_vf);
-    hipLaunchKernelGGL(reduce_kernel, grid, dim3(RED_THREADS), 0, s, R);
+    R.segs = c->d_segs; R.segcnt = c->d_segcnt;
+    const int nseg = (nblk + SEG - 1) / SEG;
+    const int ncol = (NACT * NF / 4 + RED_THREADS - 1) / RED_THREADS;
+    if (nseg > 0) {
+        hipLaunchKernelGGL(reduce1_kernel, dim3(ncol, nseg, c->n_vf), dim3(RED_THREADS), 0, s, R);
+        SCG_HIP(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(reduce2_kernel, dim3(ncol, c->n_vf), dim3(RED_THREADS), 0, s, R);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
@@ -803,6 +957,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     A.n = c->cfg.n_envs; A.k_lo = 0; A.k_hi = c->n_vf - 1;
     A.enabled = enabled_mask; A.learn = (flags & SCG_STEP_LEARN) ? 1u : 0u; A.t = t;
     if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
+    A.diag = (flags >> 12) & 0xfu;       // diagnostic only: early exits for phase timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof_on) {
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
