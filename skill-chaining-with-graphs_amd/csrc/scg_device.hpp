@@ -116,7 +116,7 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 
 // ------------------------------------------------------------------ SPEC §1.3
 struct MapScalars {
-    float hstep, R2, TX, TY, TR2, reach2;
+    float hstep, R2, TX, TY, TR2, R, TR;
     int n_edges, n_starts;
 };
 
@@ -146,9 +146,14 @@ __device__ __forceinline__ float edge_d2(const float4 ea, const float inv_len2, 
     return fmaf(by, by, bx * bx);
 }
 
-// One env step. `edges` = LDS table [n_edges][8]. Returns reward; goal flag by reference.
-__device__ __forceinline__ float pinball_step(const float *edges, const MapScalars &ms, float &x, float &y,
-                                              float &vx, float &vy, int a, bool &goal_out) {
+constexpr int CELL_G = 32;         // candidate-mask grid: 32 x 32 cells over the unit square
+
+// One env step. `edges` = LDS table [n_edges][8]; `cellmask` = global table [32*32][4] of 64-bit edge masks
+// (edges that can come within reach of any point of the cell at any legal speed — built on the host by
+// scg_set_map). NW = number of 64-bit mask words in use (n_edges <= 64 NW). Returns reward; goal by reference.
+template <int NW>
+__device__ __forceinline__ float pinball_step(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
+                                              float &x, float &y, float &vx, float &vy, int a, bool &goal_out) {
     const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
     const float4 *E4 = reinterpret_cast<const float4 *>(edges);
     // impulse + clip first: the speed |v| is now fixed for the whole step (mirror / reversal keep it)
@@ -161,59 +166,68 @@ __device__ __forceinline__ float pinball_step(const float *edges, const MapScala
     // Conservative candidate set (SPEC §1.3, last paragraph): the ball travels at most 21 |v| R/20 this step,
     // so only edges within R (1 + 1.05 |v|) of the start position can be intercepted. The bound need not be
     // exact, only safe: 1.10 instead of 1.05 and +2 % on the radius swallow the approximate sqrt and rounding.
+    // The cell mask narrows 47..256 edges to the handful near the ball's cell; those are refined exactly.
     const float spd = __builtin_sqrtf(fmaf(vy, vy, vx * vx));
     const float rr = fmaf(1.10f, spd, 1.02f);
     const float reach2 = ms.R2 * rr * rr;
-    uint64_t cand[MAX_EDGES / 64];
+    const int cxi = min(max((int)(x * (float)CELL_G), 0), CELL_G - 1);
+    const int cyi = min(max((int)(y * (float)CELL_G), 0), CELL_G - 1);
+    const uint64_t *cm = cellmask + (size_t)(cyi * CELL_G + cxi) * 4;
+    uint64_t cand[NW];
     bool any = false;
 #pragma unroll
-    for (int g = 0; g < MAX_EDGES / 64; ++g) {
-        uint64_t m = 0;
-        if (g * 64 < ms.n_edges) {
-            const int jn = min(64, ms.n_edges - g * 64);
-#pragma unroll 4
-            for (int j = 0; j < jn; ++j) {
-                const float4 ea = E4[2 * (g * 64 + j)];
-                const float inv = edges[8 * (g * 64 + j) + 4];
-                if (edge_d2(ea, inv, x, y) <= reach2) m |= (1ull << j);
-            }
+    for (int g = 0; g < NW; ++g) {
+        uint64_t m = cm[g], out = 0;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int j = g * 64 + b;
+            if (edge_d2(E4[2 * j], edges[8 * j + 4], x, y) <= reach2) out |= (1ull << b);
         }
-        cand[g] = m;
-        any = any || (m != 0);
+        cand[g] = out;
+        any = any || (out != 0);
     }
+    // the goal disc can only be entered if it starts within reach as well
+    const float gx0 = x - ms.TX, gy0 = y - ms.TY;
+    const float gr = ms.TR + (rr - 1.0f) * ms.R;                       // TR + 1.10 |v| R + 2 % R
+    const bool near_goal = fmaf(gy0, gy0, gx0 * gx0) <= gr * gr;
     bool goal = false;
     const float h = ms.hstep;
     const bool wave_any = __ballot(any) != 0;             // wave-uniform: nobody near an edge -> free flight
+    const bool wave_goal = __ballot(near_goal) != 0;
     for (int i = 0; i < 20; ++i) {
         x = fmaf(vx, h, x); y = fmaf(vy, h, y);
         int nhit = 0, first = -1;
-        if (wave_any)
+        if (wave_any) {
 #pragma unroll
-        for (int g = 0; g < MAX_EDGES / 64; ++g) {
-            uint64_t m = cand[g];
-            while (m) {
-                const int j = g * 64 + __builtin_ctzll(m);
-                m &= m - 1;
-                const float4 ea = E4[2 * j];
-                const float inv = edges[8 * j + 4];
-                if (intercept(ea, inv, ms.R2, x, y, vx, vy)) {
-                    if (nhit == 0) first = j;
-                    ++nhit;
+            for (int g = 0; g < NW; ++g) {
+                uint64_t m = cand[g];
+                while (m) {
+                    const int j = g * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float4 ea = E4[2 * j];
+                    const float inv = edges[8 * j + 4];
+                    if (intercept(ea, inv, ms.R2, x, y, vx, vy)) {
+                        if (nhit == 0) first = j;
+                        ++nhit;
+                    }
                 }
             }
+            if (nhit == 1) {
+                const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
+                const float pr = fmaf(vy, uy, vx * ux);
+                const float tp = pr + pr;
+                const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
+                vx = nvx; vy = nvy;
+                if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
+            } else if (nhit > 1) {
+                vx = -vx; vy = -vy;
+            }
         }
-        if (nhit == 1) {
-            const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
-            const float pr = fmaf(vy, uy, vx * ux);
-            const float tp = pr + pr;
-            const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
-            vx = nvx; vy = nvy;
-            if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
-        } else if (nhit > 1) {
-            vx = -vx; vy = -vy;
+        if (wave_goal) {
+            const float gx = x - ms.TX, gy = y - ms.TY;
+            if (fmaf(gy, gy, gx * gx) < ms.TR2) { goal = true; break; }
         }
-        const float gx = x - ms.TX, gy = y - ms.TY;
-        if (fmaf(gy, gy, gx * gx) < ms.TR2) { goal = true; break; }
     }
     float reward;
     if (goal) {
@@ -225,6 +239,14 @@ __device__ __forceinline__ float pinball_step(const float *edges, const MapScala
     }
     goal_out = goal;
     return reward;
+}
+
+// dispatch on the number of mask words the map needs (wave-uniform)
+__device__ __forceinline__ float pinball_step_any(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
+                                                  float &x, float &y, float &vx, float &vy, int a, bool &goal) {
+    if (ms.n_edges <= 64) return pinball_step<1>(edges, cellmask, ms, x, y, vx, vy, a, goal);
+    if (ms.n_edges <= 128) return pinball_step<2>(edges, cellmask, ms, x, y, vx, vy, a, goal);
+    return pinball_step<4>(edges, cellmask, ms, x, y, vx, vy, a, goal);
 }
 
 // ------------------------------------------------------------------ SPEC §4.1

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -44,6 +45,22 @@ static_assert(OFF_POW % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
+// Diagnostic build only (make stamps -> libscg_hip_stamps.so, tools/stamp_report.py): wave 0 of every
+// workgroup accumulates s_memtime deltas per kernel section into A.stamps[block][section]. The shipped
+// library is built without SCG_STAMPS and contains none of this.
+#ifdef SCG_STAMPS
+#define SCG_STAMP(SEC)                                                                   \
+    do {                                                                                 \
+        if (MODE == MODE_FUSED && A.stamps && tid == 0) {                                \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
+            A.stamps[(size_t)blockIdx.x * 16 + (SEC)] += t_ - stamp_prev;                \
+            stamp_prev = t_;                                                             \
+        }                                                                                \
+    } while (0)
+#else
+#define SCG_STAMP(SEC) do { } while (0)
+#endif
+
 struct StepArgs {
     // env state (FUSED: in/out; TRANS/QVAL: in)
     float *x, *y, *vx, *vy;
@@ -57,9 +74,11 @@ struct StepArgs {
     const float *W;                // [n_vf][5][1296] (QVAL: one VF)
     const float *clf;              // [n_vf][8]
     const float *edges;            // device [n_edges][8]
+    const uint64_t *cellmask;      // device [32*32][4] candidate-edge masks per grid cell
     const float *starts;           // device [n_starts][2]
     float *slabs;                  // [nblk][n_vf][5][1296]
     int32_t *cnts;                 // [nblk][n_vf]
+    unsigned long long *stamps;    // diagnostic build only
     int32_t n, n_vf, k_lo, k_hi;
     uint32_t enabled, learn, diag;
     uint64_t t, seed;
@@ -106,6 +125,9 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     const int e0 = b * BLOCK_ENVS;
     const int nb = min(BLOCK_ENVS, A.n - e0);
     const int N = A.n;
+#ifdef SCG_STAMPS
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
 
     if (MODE == MODE_FUSED) {
         for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
@@ -134,15 +156,16 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 }
                 const int a = explore ? a_rand : a_greedy;
                 float sx = A.x[e], sy = A.y[e], svx = A.vx[e], svy = A.vy[e];
+                const int ep0 = A.ep_steps[e], o = A.option_id[e], osteps = A.opt_steps[e];   // early: latency hides under the physics
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
                 if (A.diag == 3) { A.action[e] = (uint8_t)a; return; }
                 // physics (SPEC §1.3)
                 bool goal;
-                const float rew = pinball_step(s_edges, A.ms, sx, sy, svx, svy, a, goal);
+                const float rew = pinball_step_any(s_edges, A.cellmask, A.ms, sx, sy, svx, svy, a, goal);
                 if (A.diag == 4) { A.reward[e] = rew + sx + sy + svx + svy; return; }
                 // bookkeeping (SPEC §1.4)
-                const int eps1 = A.ep_steps[e] + 1;
+                const int eps1 = ep0 + 1;
                 const bool timeout = !goal && eps1 >= A.max_ep;
                 const int dn = goal ? 1 : (timeout ? 2 : 0);
                 float nx = sx, ny = sy, nvx = svx, nvy = svy;
@@ -153,8 +176,6 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_s[4 * BLOCK_ENVS + i] = nx; s_s[5 * BLOCK_ENVS + i] = ny;
                 s_s[6 * BLOCK_ENVS + i] = nvx; s_s[7 * BLOCK_ENVS + i] = nvy;
                 // options (SPEC §4.2)
-                const int o = A.option_id[e];
-                const int osteps = A.opt_steps[e];
                 bool keep = false;
                 float ro = 0.0f, co = 0.0f;
                 if (o >= 1) {
@@ -204,6 +225,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     __syncthreads();
 
     if (MODE == MODE_FUSED && A.diag >= 2) return;
+    SCG_STAMP(0);   // phase P
     // ------------------------------------------------------------------ phase Z (SPEC §3)
     {
         const int i = tid & (BLOCK_ENVS - 1), sg = tid >> 8;
@@ -274,7 +296,12 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
     };
 
-    // R = W_k in loops A and B, the gradient accumulator in loop C: never live together. Stored as action
+    const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets of the lane's main / tail slots
+    const uint32_t w_vt = (uint32_t)(tl * 36 + 32 + (lane & 3)) * 4u;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A.W), 0, (MODE == MODE_QVAL ? 1 : A.n_vf) * NACT * NF * 4, 0x00020000);
+
+    // R = W_k in loop A (the accumulator of loop BC reuses its registers). Stored as action
     // pairs (a0,a1), (a2,a3) + a4 so that loop A's packed FMAs take real register pairs: a {w,w} splat
     // operand costs a second VGPR per weight once hipcc hoists it out of the group loop (it did: 2 x 105).
     v2f Rp[2][NSLOT];
@@ -289,28 +316,31 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 // table reads of slot J (compile-time J): x[4] / y[4] of the slot's AB entry
 #define SCG_LDX(J) ((J) < 18 ? t_m[4 * (J)] : ((J) < 20 ? t_t[32 * ((J)-18)] : t_t2[0]))
 #define SCG_LDY(J) ((J) < 18 ? t_m[4 * (J) + 1] : ((J) < 20 ? t_t[32 * ((J)-18) + 1] : t_t2[1]))
-// The slot loop shared by loops A, B and C: for j = 0..20 form phi of the group's 4 items (pa = items 0,1;
-// pb = items 2,3; packed fp32) from the tables at T_M/T_T/T_T2 and the lane's column factors, then run BODY.
-// Table reads are register-pipelined two slots ahead and sched_barrier pins that pattern (left alone,
-// hipcc hoists all 42 ds_read_b128 of a group and spills hundreds of VGPRs).
-#define SCG_SLOT_LOOP(...)                                                                              \
+// The slot loop shared by loops A, B and C: for j = 0..20 form phi of the quad's 4 items (pa = items 0,1;
+// pb = items 2,3; packed fp32) from the tables at t_m/t_t/t_t2 and the lane's column factors, then run BODY.
+// Table reads are register-pipelined DEPTH slots ahead and sched_barrier pins that pattern (left alone,
+// hipcc hoists all 42 ds_read_b128 of a quad and spills hundreds of VGPRs). Loop A is register-bound
+// (DEPTH 1); loops B and C have only ~7 instructions per slot, so they run 4 slots ahead.
+#define SCG_SLOT_LOOP_D(DEPTH, ...)                                                                     \
     {                                                                                                   \
-        float4 ax0 = SCG_LDX(0), ay0 = SCG_LDY(0);                                                      \
+        float4 axq[DEPTH + 1], ayq[DEPTH + 1];                                                          \
+        _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = SCG_LDX(d_); ayq[d_] = SCG_LDY(d_); } \
         _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                                             \
-            float4 ax1 = ax0, ay1 = ay0;                                                                \
-            if (j + 1 < NSLOT) { ax1 = SCG_LDX(j + 1); ay1 = SCG_LDY(j + 1); }                          \
+            if (j + DEPTH < NSLOT) { axq[DEPTH] = SCG_LDX(j + DEPTH); ayq[DEPTH] = SCG_LDY(j + DEPTH); } \
             if (j == 18) { ccx = t_ct0[boff]; ccy = t_ct0[boff + 1]; }   /* tail column factor from here on */ \
-            const float4 cx_ = ccx, cy_ = ccy;                                                          \
+            const float4 ax0 = axq[0], ay0 = ayq[0], cx_ = ccx, cy_ = ccy;                              \
             const v2f ax01 = {ax0.x, ax0.y}, ax23 = {ax0.z, ax0.w}, ay01 = {ay0.x, ay0.y}, ay23 = {ay0.z, ay0.w}; \
             const v2f cx01 = {cx_.x, cx_.y}, cx23 = {cx_.z, cx_.w}, cy01 = {cy_.x, cy_.y}, cy23 = {cy_.z, cy_.w}; \
             v2f pa = __builtin_elementwise_fma(-ay01, cy01, ax01 * cx01);                               \
             v2f pb = __builtin_elementwise_fma(-ay23, cy23, ax23 * cx23);                               \
             if (j == 20) { pa = pa * (v2f){m20, m20}; pb = pb * (v2f){m20, m20}; }                      \
             { __VA_ARGS__ }                                                                             \
-            ax0 = ax1; ay0 = ay1;                                                                       \
+            _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = axq[d_ + 1]; ayq[d_] = ayq[d_ + 1]; } \
             __builtin_amdgcn_sched_barrier(0);                                                          \
         }                                                                                               \
     }
+#define SCG_SLOT_LOOP(...) SCG_SLOT_LOOP_D(1, __VA_ARGS__)
+#define SCG_SLOT_LOOP4(...) SCG_SLOT_LOOP_D(2, __VA_ARGS__)
 // quad prologue: wait for this quad's tables, start the next quad's (index QN, if < NQ), bind table pointers
 #define SCG_GROUP_BEGIN(LST, CNT, QN, NQ, SG)                                                           \
     const int boff = (par & 1) * (TAB_FLOATS / 4);                                                      \
@@ -384,6 +414,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
         __syncthreads();
         if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = nupd;
+        SCG_STAMP(k == 0 ? 1 : 8);    // phase Z (first pass only) + list build
         if (n_ev + nupd == 0) continue;
 
         // W_k -> LDS once per workgroup (coalesced float4; the staging area is the reduction buffer, idle
@@ -406,6 +437,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             __syncthreads();                                       // the staging area becomes table scratch
         }
 
+        SCG_STAMP(k == 0 ? 2 : 9);    // W staging
         // ---- loop A (W_k live): Q_k(s_next, .) of one quad at a time -> qcache, max -> s_maxq[env]
         {
             const int nq = (n_ev + 3) >> 2;
@@ -457,65 +489,45 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             }
         }
         if (MODE == MODE_QVAL || nupd == 0) continue;
+        SCG_STAMP(k == 0 ? 3 : 10);   // loop A (wave 0's share)
         __syncthreads();                                   // s_maxq crosses waves (loop B deals quads differently)
 
-        // ---- loop B (W_k live): Q_k(s, a_t) -> TD error -> s_delta[env], one action run at a time
-        auto loop_b = [&](auto aa_c) {
-            constexpr int AA = decltype(aa_c)::value;
-            const int cnt = run_len[AA], nq = (cnt + 3) >> 2;
-            const uint16_t *lst = s_ulist + run_off[AA];
-            const int q0 = (wave - qbase[AA]) & (WAVES - 1);          // first quad of this run dealt to this wave
-            if (q0 >= nq) return;
-            int ie[GI], par = 0;
-            bool ok[GI];
-            wave_lds_sync();
-            load_group(lst, cnt, 4 * q0, ie, ok);
-            gen_tables(ie, 0, scr0);
-            for (int qi = q0; qi < nq; qi += WAVES) {
-                SCG_GROUP_BEGIN(lst, cnt, qi + WAVES, nq, 0)
-                v2f qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
-                SCG_SLOT_LOOP(
-                    if constexpr (AA < 4) {
-                        const v2f w2 = {SCG_R(AA, j), SCG_R(AA, j)};                  // op_sel splat of a pair half
-                        qa = __builtin_elementwise_fma(w2, pa, qa);
-                        qb = __builtin_elementwise_fma(w2, pb, qb);
-                    } else {
-                        qa.x = fmaf(R4[j], pa.x, qa.x); qa.y = fmaf(R4[j], pa.y, qa.y);
-                        qb.x = fmaf(R4[j], pb.x, qb.x); qb.y = fmaf(R4[j], pb.y, qb.y);
-                    })
-                float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
-                wave_sum_n<GI>(qs);
-#pragma unroll
-                for (int g = 0; g < GI; ++g) {
-                    if (ok[g]) {
-                        const int i = ie[g];
-                        const float r = (k == 0) ? s_r0[i] : s_ro[i];
-                        const float cont = (k == 0) ? s_c0[i] : s_co[i];
-                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[i], r) : r;
-                        if (lane == 0) s_delta[i] = target - qs[g];    // read back by this same wave in loop C
-                    }
-                }
-                SCG_GROUP_END
-            }
-        };
-        loop_b(std::integral_constant<int, 0>{}); loop_b(std::integral_constant<int, 1>{});
-        loop_b(std::integral_constant<int, 2>{}); loop_b(std::integral_constant<int, 3>{});
-        loop_b(std::integral_constant<int, 4>{});
-
-        // ---- loop C (accumulator live): acc[a][f] = fma(delta, phi_f(s), acc[a][f]), quads in order.
-        // A separate float array (W's register pairs are dead by now and get reused).
+        SCG_STAMP(k == 0 ? 4 : 11);   // wait for the other waves' loop A
+        // ---- loop BC (accumulator live, one row of W_k at a time): for each action run, for this wave's quads:
+        //   pass 1 over the slots: phi(s) -> Q_k(s, a) partials -> butterfly -> TD error delta
+        //   pass 2 over the slots: phi(s) again (same tables, re-read from LDS) -> acc[a][f] = fma(delta, phi, acc)
+        // Specialised per action, the loop needs only row a of W_k (21 VGPRs, re-fetched per run through
+        // the buffer descriptor) next to the 105-VGPR accumulator, so Q(s,a) and the accumulate share one
+        // table build and one loop — they used to be two full loops (B and C) over the same items.
         float Acc[NACT][NSLOT];
 #pragma unroll
         for (int a = 0; a < NACT; ++a) {
 #pragma unroll
             for (int j = 0; j < NSLOT; ++j) Acc[a][j] = 0.0f;
         }
-        auto loop_c = [&](auto aa_c) {
+        const uint32_t kbase = (uint32_t)k * (NACT * NF * 4);
+        auto loop_bc = [&](auto aa_c) {
             constexpr int AA = decltype(aa_c)::value;
             const int cnt = run_len[AA], nq = (cnt + 3) >> 2;
             const uint16_t *lst = s_ulist + run_off[AA];
-            const int q0 = (wave - qbase[AA]) & (WAVES - 1);
+            const int q0 = (wave - qbase[AA]) & (WAVES - 1);          // first quad of this run dealt to this wave
             if (q0 >= nq) return;
+            v2f Wp[(NSLOT + 1) / 2];                                  // row AA of W_k as slot pairs (real pairs:
+                                                                      // a {w,w} splat would cost 2 VGPRs per weight)
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                float v;
+                if (j < 18) {
+                    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        w_rsrc, w_vm, kbase + (uint32_t)(AA * NF + 72 * j) * 4u, 0));
+                } else {
+                    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        w_rsrc, (j < 20 || v20) ? w_vt : 0u, kbase + (uint32_t)(AA * NF + 576 * (j - 18)) * 4u, 0));
+                    if (j == 20) v = v20 ? v : 0.0f;
+                }
+                if (j & 1) Wp[j >> 1].y = v; else Wp[j >> 1].x = v;
+            }
+            Wp[NSLOT / 2].y = 0.0f;
             int ie[GI], par = 0;
             bool ok[GI];
             wave_lds_sync();
@@ -523,10 +535,26 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             gen_tables(ie, 0, scr0);
             for (int qi = q0; qi < nq; qi += WAVES) {
                 SCG_GROUP_BEGIN(lst, cnt, qi + WAVES, nq, 0)
+                const float4 cmx_ = ccx, cmy_ = ccy;                  // main column factor, needed again in pass 2
+                v2f qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
+                SCG_SLOT_LOOP4(
+                    const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
+                    const v2f w2 = {wj, wj};                              // op_sel splat of a pair half
+                    qa = __builtin_elementwise_fma(w2, pa, qa);
+                    qb = __builtin_elementwise_fma(w2, pb, qb);)
+                float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
+                wave_sum_n<GI>(qs);
                 float dl[GI];
 #pragma unroll
-                for (int g = 0; g < GI; ++g) dl[g] = ok[g] ? s_delta[ie[g]] : 0.0f;     // padding item: += 0
-                SCG_SLOT_LOOP(
+                for (int g = 0; g < GI; ++g) {
+                    const int i = ie[g];
+                    const float r = (k == 0) ? s_r0[i] : s_ro[i];
+                    const float cont = (k == 0) ? s_c0[i] : s_co[i];
+                    const float target = cont > 0.0f ? fmaf(cont, s_maxq[i], r) : r;
+                    dl[g] = ok[g] ? target - qs[g] : 0.0f;            // padding item: += 0
+                }
+                ccx = cmx_; ccy = cmy_;
+                SCG_SLOT_LOOP4(
                     Acc[AA][j] = fmaf(dl[0], pa.x, Acc[AA][j]);
                     Acc[AA][j] = fmaf(dl[1], pa.y, Acc[AA][j]);
                     Acc[AA][j] = fmaf(dl[2], pb.x, Acc[AA][j]);
@@ -534,39 +562,51 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 SCG_GROUP_END
             }
         };
-        loop_c(std::integral_constant<int, 0>{}); loop_c(std::integral_constant<int, 1>{});
-        loop_c(std::integral_constant<int, 2>{}); loop_c(std::integral_constant<int, 3>{});
-        loop_c(std::integral_constant<int, 4>{});
-
-        // block partial: ((acc_0 + acc_1) + ...) + acc_7, through LDS in wave order (the buffer aliases
-        // the table scratch, so every wave must be out of loop C first)
-        __syncthreads();
-        for (int w = 0; w < WAVES; ++w) {
-            if (wave == w) {
+        loop_bc(std::integral_constant<int, 0>{}); loop_bc(std::integral_constant<int, 1>{});
+        loop_bc(std::integral_constant<int, 2>{}); loop_bc(std::integral_constant<int, 3>{});
+        loop_bc(std::integral_constant<int, 4>{});
+        SCG_STAMP(k == 0 ? 6 : 13);   // loop C
+        // block partial P = ((acc_0 + acc_1) + ...) + acc_7 (SPEC §5), three slots at a time: every wave
+        // parks its 15 values per lane (5 actions x 3 slots) in the table scratch, then each of the 512
+        // threads adds the 8 waves' values of ~2 outputs in wave order and stores them straight into the
+        // block's slab. (The first version took 8 sequential wave turns of 105 LDS read-modify-writes:
+        // 37k cycles per pass, a third of the kernel.)
+        {
+            float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
+            float *park = s_scr + wave * (15 * 64) + lane;             // [wave][15][64]
+#pragma unroll
+            for (int c = 0; c < NSLOT / 3; ++c) {
+                __syncthreads();                                       // scratch free (tables / previous chunk)
 #pragma unroll
                 for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-                    for (int j = 0; j < 18; ++j) {
-                        float *p = &buf_m[a * NF + 72 * j];
-                        *p = (w == 0) ? Acc[a][j] : *p + Acc[a][j];
-                    }
+                    for (int jj = 0; jj < 3; ++jj) park[(a * 3 + jj) * 64] = Acc[a][3 * c + jj];
+                }
+                __syncthreads();
+                for (int o = tid; o < 15 * 64; o += THREADS) {
+                    const int l = o & 63, v15 = o >> 6;
+                    const int a = v15 / 3, j = 3 * c + (v15 - 3 * a);
+                    float sum = s_scr[o];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        if (t < 2 || v20) {
-                            float *p = &buf_t[a * NF + 576 * t];
-                            *p = (w == 0) ? Acc[a][18 + t] : *p + Acc[a][18 + t];
-                        }
+                    for (int w = 1; w < WAVES; ++w) sum = sum + s_scr[w * (15 * 64) + o];
+                    // canonical feature index of (lane l, slot j) — SPEC §3.1
+                    int f = -1;
+                    if (j < 18) f = (2 * j + (l >> 5)) * 36 + (l & 31);
+                    else {
+                        const int idx = 64 * (j - 18) + l;
+                        if (idx < 144) f = (idx >> 2) * 36 + 32 + (idx & 3);
                     }
+                    if (f >= 0) slab[a * NF + f] = sum;
                 }
             }
-            __syncthreads();
         }
-        float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
-        for (int f = tid; f < NACT * NF; f += THREADS) slab[f] = s_buf[f];
+        SCG_STAMP(k == 0 ? 7 : 14);   // block reduction + slab store
     }
 #undef SCG_LDX
 #undef SCG_LDY
 #undef SCG_SLOT_LOOP
+#undef SCG_SLOT_LOOP4
+#undef SCG_SLOT_LOOP_D
 #undef SCG_GROUP_BEGIN
 #undef SCG_GROUP_END
 #undef SCG_R
@@ -681,7 +721,7 @@ __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, co
 // un-fused kernels
 __global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y, float *vx, float *vy,
                                                       const uint8_t *action, float *reward, uint8_t *goal,
-                                                      const float *edges, MapScalars ms) {
+                                                      const float *edges, const uint64_t *cellmask, MapScalars ms) {
     __shared__ __attribute__((aligned(16))) float s_edges[MAX_EDGES * 8];
     for (int i = threadIdx.x; i < ms.n_edges * 8; i += 256) s_edges[i] = edges[i];
     __syncthreads();
@@ -689,7 +729,7 @@ __global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y,
     if (e >= n) return;
     float sx = x[e], sy = y[e], svx = vx[e], svy = vy[e];
     bool g;
-    const float r = pinball_step(s_edges, ms, sx, sy, svx, svy, action[e], g);
+    const float r = pinball_step_any(s_edges, cellmask, ms, sx, sy, svx, svy, action[e], g);
     x[e] = sx; y[e] = sy; vx[e] = svx; vy[e] = svy;
     reward[e] = r; goal[e] = g ? 1 : 0;
 }
@@ -770,6 +810,8 @@ struct scg_ctx {
     bool have_map;
     MapScalars ms;
     float *d_edges, *d_starts, *d_scale;
+    uint64_t *d_cellmask;
+    unsigned long long *d_stamps;   // diagnostic build only (NULL otherwise)
     float *d_slabs;
     int32_t *d_cnts;
     float *d_G;
@@ -849,6 +891,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_nk, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_edges, MAX_EDGES * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_cellmask, (size_t)CELL_G * CELL_G * 4 * sizeof(uint64_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_G, 0, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_nk, 0, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
@@ -864,6 +907,10 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         scg_destroy(c);
         return st;
     }
+#ifdef SCG_STAMPS
+    if (hipMalloc(&c->d_stamps, (size_t)c->nblk * 16 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 16 * sizeof(unsigned long long));
+#endif
     c->G_out = c->d_G; c->nk_out = c->d_nk;
     *out = c;
     return SCG_OK;
@@ -873,7 +920,7 @@ int scg_destroy(scg_ctx *c) {
     if (!c) return SCG_OK;
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
     (void)hipFree(c->d_segs); (void)hipFree(c->d_segcnt);
-    (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale);
+    (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -906,7 +953,29 @@ int scg_set_map(scg_ctx *c, const float *edges, int32_t n_edges, const float *st
     const float R = map_scalars[0];
     c->ms.hstep = map_scalars[1]; c->ms.R2 = map_scalars[2];
     c->ms.TX = map_scalars[3]; c->ms.TY = map_scalars[4]; c->ms.TR2 = map_scalars[5];
-    c->ms.reach2 = (float)((4.25 * (double)R) * (4.25 * (double)R));
+    c->ms.R = R; c->ms.TR = (float)(std::sqrt((double)map_scalars[5]) * 1.0001);
+    // Candidate masks (an internal acceleration table, not part of the arithmetic contract): cell (cx,cy)
+    // lists every edge within  R(1.02 + 1.10*|v|max) + half a cell diagonal  of the cell centre, so the
+    // mask of the ball's cell is a superset of the edges the per-step bound of pinball_step() can admit.
+    {
+        std::vector<uint64_t> cm((size_t)CELL_G * CELL_G * 4, 0);
+        const double vmax = 2.0 * std::sqrt(2.0) * 1.001;
+        const double reach = (double)R * (1.02 + 1.10 * vmax) * 1.01 + 0.5 * std::sqrt(2.0) / CELL_G + 1e-6;
+        for (int cy = 0; cy < CELL_G; ++cy)
+            for (int cx = 0; cx < CELL_G; ++cx) {
+                const double px = (cx + 0.5) / CELL_G, py = (cy + 0.5) / CELL_G;
+                for (int j = 0; j < n_edges; ++j) {
+                    const float *E = edges + 8 * j;
+                    const double dx = px - E[0], dy = py - E[1];
+                    double t = (dx * E[2] + dy * E[3]) * E[4];
+                    t = t < 0 ? 0 : (t > 1 ? 1 : t);
+                    const double qx = E[0] + E[2] * t - px, qy = E[1] + E[3] * t - py;
+                    if (std::sqrt(qx * qx + qy * qy) <= reach)
+                        cm[((size_t)cy * CELL_G + cx) * 4 + (j >> 6)] |= (1ull << (j & 63));
+                }
+            }
+        SCG_HIP(c, hipMemcpy(c->d_cellmask, cm.data(), cm.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
     c->ms.n_edges = n_edges; c->ms.n_starts = n_starts;
     c->have_map = true;
     return SCG_OK;
@@ -919,8 +988,9 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.gamma = c->cfg.gamma; A.epsilon = c->cfg.epsilon; A.r_succ = c->cfg.r_option_success;
     A.max_ep = c->cfg.max_episode_steps; A.max_opt = c->cfg.max_option_steps;
     A.ms = c->ms;
-    A.edges = c->d_edges; A.starts = c->d_starts;
+    A.edges = c->d_edges; A.starts = c->d_starts; A.cellmask = c->d_cellmask;
     A.slabs = c->d_slabs; A.cnts = c->d_cnts;
+    A.stamps = c->d_stamps;
 }
 
 static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStream_t s) {
@@ -977,6 +1047,15 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     return SCG_OK;
 }
 
+#ifdef SCG_STAMPS
+extern "C" int scg_diag_stamps(scg_ctx *c, unsigned long long *host_out /*[nblk][16]*/, int32_t reset) {
+    if (!c || !c->d_stamps) return SCG_ERR_STATE;
+    if (host_out && hipMemcpy(host_out, c->d_stamps, (size_t)c->nblk * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return SCG_ERR_HIP;
+    if (reset) (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 16 * sizeof(unsigned long long));
+    return SCG_OK;
+}
+#endif
+
 int scg_profile_reset(scg_ctx *c, int32_t enable) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_profile_reset: null ctx");
     c->prof_on = enable != 0;
@@ -1031,7 +1110,7 @@ int scg_pinball_step(scg_ctx *c, int32_t n, float *x, float *y, float *vx, float
         return fail(c, SCG_ERR_INVALID, "scg_pinball_step: bad argument");
     if (n == 0) return SCG_OK;
     hipLaunchKernelGGL(pinball_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       n, x, y, vx, vy, action, reward, goal, c->d_edges, c->ms);
+                       n, x, y, vx, vy, action, reward, goal, c->d_edges, c->d_cellmask, c->ms);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }

@@ -1,0 +1,33 @@
+"""Diagnostic: per-section cycle shares of the fused kernel from the SCG_STAMPS build (wave 0 of each block).
+Usage: python tools/stamp_report.py [--options N] [--steps K]   (needs `make -C .../csrc stamps`)."""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+ap = argparse.ArgumentParser(); ap.add_argument("--options", type=int, default=5); ap.add_argument("--steps", type=int, default=50)
+args = ap.parse_args()
+from skill_chaining_with_graphs_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libscg_hip_stamps.so")
+import numpy as np, torch
+import bench
+from skill_chaining_with_graphs_amd import SkillChainingAgent
+n = 65536
+agent = SkillChainingAgent(bench.MAP, n, args.options, seed=0, **bench.HP)
+agent.clf.copy_(torch.as_tensor(bench.chain_discs(agent.map, args.options)))
+for k in range(1, args.options + 1): agent.enable_option(k)
+agent.init_weights(std=1e-3); agent.domain.reset_random(seed=1000)
+for _ in range(10): agent.step_batch()
+torch.cuda.synchronize()
+lib, ctx = agent.ctx.lib, agent.ctx._ctx
+lib.scg_diag_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+nblk = n // 256
+lib.scg_diag_stamps(ctx, None, 1)
+for _ in range(args.steps): agent.step_batch()
+torch.cuda.synchronize()
+out = np.zeros((nblk, 16), np.uint64)
+lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
+names = ["phase P", "root: phaseZ+lists", "root: W staging", "root: loop A", "root: wait A", "root: loop B", "root: loop C",
+         "root: reduce+slab", "opt: lists", "opt: W staging", "opt: loop A", "opt: wait A", "opt: loop B", "opt: loop C", "opt: reduce+slab", "-"]
+mean = out.astype(np.float64).mean(0) / args.steps
+tot = mean.sum()
+print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
+for nme, v in zip(names, mean): print(f"  {nme:22s} {v:10.0f}  {100*v/tot:5.1f} %")
