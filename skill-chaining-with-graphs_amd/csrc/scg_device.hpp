@@ -114,6 +114,43 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
     }
 }
 
+// ---- transposed butterflies (same pairing tree as wave_sum: stages xor 1, 2, 4, 8, 16, 32; only the
+// lanes that end up holding each sum differ). Lanes exchange HALF of their values at the first two
+// stages instead of all of them: after xor-1 and xor-2 lane l holds the quad-complete partial sums of
+// item (l & 3) only, so the remaining four stages run on a quarter of the values.
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float swz_xor4(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }
+__device__ __forceinline__ float swz_xor8(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x201F)); }
+
+// in: v[4*M] = M values for each of 4 items (item-major). out: o[M] = full 64-lane sums of item (lane & 3).
+template <int M>
+__device__ __forceinline__ void quad_transposed_sum(const float (&v)[4 * M], float (&o)[M], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float r0[M], r1[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) {      // xor 1: items 0<->1 and 2<->3
+        r0[a] = (b0 ? v[M + a] : v[a]) + dpp_xor1(b0 ? v[a] : v[M + a]);
+        r1[a] = (b0 ? v[3 * M + a] : v[2 * M + a]) + dpp_xor1(b0 ? v[2 * M + a] : v[3 * M + a]);
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a) o[a] = (b1 ? r1[a] : r0[a]) + dpp_xor2(b1 ? r0[a] : r1[a]);   // xor 2
+#pragma unroll
+    for (int a = 0; a < M; ++a) o[a] = o[a] + swz_xor4(o[a]);
+#pragma unroll
+    for (int a = 0; a < M; ++a) o[a] = o[a] + swz_xor8(o[a]);
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[a]), __float_as_uint(o[a]), false, false);
+        o[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[a]), __float_as_uint(o[a]), false, false);
+        o[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+
 // ------------------------------------------------------------------ SPEC §1.3
 struct MapScalars {
     float hstep, R2, TX, TY, TR2, R, TR;

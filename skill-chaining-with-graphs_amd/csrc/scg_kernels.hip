@@ -279,7 +279,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 for (int g = 0; g < GI; ++g) {
                     const float2 *pw = s_pow + (ie[g] * 2 + sg) * POW_N;
                     const float2 z = cmul(pw[goa[r]], pw[gob[r]]);
-                    zx[g] = z.x; zy[g] = z.y;
+                    zx[g] = z.x; zy[g] = (64 * r + lane < 36) ? -z.y : z.y;   // AB entries hold -Im: phi = fma(-Im ab, Im cd, ..) needs no sign flip
                 }
                 float4 *d4 = reinterpret_cast<float4 *>(dst) + 2 * (64 * r + lane);
                 d4[0] = make_float4(zx[0], zx[1], zx[2], zx[3]);
@@ -305,12 +305,14 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     // pairs (a0,a1), (a2,a3) + a4 so that loop A's packed FMAs take real register pairs: a {w,w} splat
     // operand costs a second VGPR per weight once hipcc hoists it out of the group loop (it did: 2 x 105).
     v2f Rp[2][NSLOT];
-    float R4[NSLOT];
-#define SCG_R(AA, J) ((AA) == 0 ? Rp[0][J].x : (AA) == 1 ? Rp[0][J].y : (AA) == 2 ? Rp[1][J].x : (AA) == 3 ? Rp[1][J].y : R4[J])
+    v2f R4p[(NSLOT + 1) / 2];                   // action 4 as slot pairs (j, j+1)
+#define SCG_R4(J) (((J) & 1) ? R4p[(J) >> 1].y : R4p[(J) >> 1].x)
+#define SCG_R(AA, J) ((AA) == 0 ? Rp[0][J].x : (AA) == 1 ? Rp[0][J].y : (AA) == 2 ? Rp[1][J].x : (AA) == 3 ? Rp[1][J].y : SCG_R4(J))
 #define SCG_R_SET(AA, J, V)                                                                     \
     do {                                                                                        \
         if ((AA) == 0) Rp[0][J].x = (V); else if ((AA) == 1) Rp[0][J].y = (V);                  \
-        else if ((AA) == 2) Rp[1][J].x = (V); else if ((AA) == 3) Rp[1][J].y = (V); else R4[J] = (V); \
+        else if ((AA) == 2) Rp[1][J].x = (V); else if ((AA) == 3) Rp[1][J].y = (V);               \
+        else if ((J) & 1) R4p[(J) >> 1].y = (V); else R4p[(J) >> 1].x = (V);                    \
     } while (0)
 
 // table reads of slot J (compile-time J): x[4] / y[4] of the slot's AB entry
@@ -331,8 +333,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             const float4 ax0 = axq[0], ay0 = ayq[0], cx_ = ccx, cy_ = ccy;                              \
             const v2f ax01 = {ax0.x, ax0.y}, ax23 = {ax0.z, ax0.w}, ay01 = {ay0.x, ay0.y}, ay23 = {ay0.z, ay0.w}; \
             const v2f cx01 = {cx_.x, cx_.y}, cx23 = {cx_.z, cx_.w}, cy01 = {cy_.x, cy_.y}, cy23 = {cy_.z, cy_.w}; \
-            v2f pa = __builtin_elementwise_fma(-ay01, cy01, ax01 * cx01);                               \
-            v2f pb = __builtin_elementwise_fma(-ay23, cy23, ax23 * cx23);                               \
+            v2f pa = __builtin_elementwise_fma(ay01, cy01, ax01 * cx01);   /* ay = -Im(AB) */             \
+            v2f pb = __builtin_elementwise_fma(ay23, cy23, ax23 * cx23);                                \
             if (j == 20) { pa = pa * (v2f){m20, m20}; pb = pb * (v2f){m20, m20}; }                      \
             { __VA_ARGS__ }                                                                             \
             _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = axq[d_ + 1]; ayq[d_] = ayq[d_ + 1]; } \
@@ -448,41 +450,43 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 gen_tables(ie, 1, scr0);
                 for (int qi = wave; qi < nq; qi += WAVES) {
                     SCG_GROUP_BEGIN(s_elist, n_ev, qi + WAVES, nq, 1)
-                    v2f q01[GI], q23[GI];
-                    float q4[GI];
+                    v2f q01[GI], q23[GI], q4a = {0.0f, 0.0f}, q4b = {0.0f, 0.0f};
 #pragma unroll
-                    for (int g = 0; g < GI; ++g) { q01[g] = (v2f){0.0f, 0.0f}; q23[g] = (v2f){0.0f, 0.0f}; q4[g] = 0.0f; }
+                    for (int g = 0; g < GI; ++g) { q01[g] = (v2f){0.0f, 0.0f}; q23[g] = (v2f){0.0f, 0.0f}; }
                     SCG_SLOT_LOOP(
                         const float ph[GI] = {pa.x, pa.y, pb.x, pb.y};
                         _Pragma("unroll") for (int g = 0; g < GI; ++g) {
                             const v2f p2 = {ph[g], ph[g]};                            // op_sel splat of a pair half
                             q01[g] = __builtin_elementwise_fma(Rp[0][j], p2, q01[g]);
                             q23[g] = __builtin_elementwise_fma(Rp[1][j], p2, q23[g]);
-                            q4[g] = fmaf(R4[j], ph[g], q4[g]);
-                        })
+                        }
+                        const v2f w4 = {SCG_R4(j), SCG_R4(j)};                        // action 4: packed over items
+                        q4a = __builtin_elementwise_fma(w4, pa, q4a);
+                        q4b = __builtin_elementwise_fma(w4, pb, q4b);)
                     float qv[GI * NACT];
 #pragma unroll
                     for (int g = 0; g < GI; ++g) {
                         qv[g * NACT + 0] = q01[g].x; qv[g * NACT + 1] = q01[g].y;
-                        qv[g * NACT + 2] = q23[g].x; qv[g * NACT + 3] = q23[g].y; qv[g * NACT + 4] = q4[g];
+                        qv[g * NACT + 2] = q23[g].x; qv[g * NACT + 3] = q23[g].y;
                     }
-                    wave_sum_n<GI * NACT>(qv);
-                    // qcache[a][env] from lanes 0..19 (lane = 5 g + a)
+                    qv[0 * NACT + 4] = q4a.x; qv[1 * NACT + 4] = q4a.y; qv[2 * NACT + 4] = q4b.x; qv[3 * NACT + 4] = q4b.y;
+                    // butterflies, transposed: lane l ends up with the five Q values of item (l & 3)
+                    float qo[NACT];
+                    quad_transposed_sum<NACT>(qv, qo, lane);
                     {
-                        float myv = 0.0f;
-#pragma unroll
-                        for (int idx = 0; idx < GI * NACT; ++idx) myv = (lane == idx) ? qv[idx] : myv;
-                        const int gl = lane / NACT, al = lane - NACT * gl;
+                        const int gl = lane & 3;
                         const int il = gl == 0 ? ie[0] : gl == 1 ? ie[1] : gl == 2 ? ie[2] : ie[3];
-                        const bool okl = gl == 0 ? ok[0] : gl == 1 ? ok[1] : gl == 2 ? ok[2] : (gl == 3 && ok[3]);
-                        if (lane < GI * NACT && okl && s_on[il] == k) A.qcache[(size_t)al * N + e0 + il] = myv;
-                    }
+                        const bool okl = gl == 0 ? ok[0] : gl == 1 ? ok[1] : gl == 2 ? ok[2] : ok[3];
+                        if (lane < GI && okl) {
+                            if (s_on[il] == k) {
 #pragma unroll
-                    for (int g = 0; g < GI; ++g) {
-                        float mx = qv[g * NACT];
+                                for (int a = 0; a < NACT; ++a) A.qcache[(size_t)a * N + e0 + il] = qo[a];
+                            }
+                            float mx = qo[0];
 #pragma unroll
-                        for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qv[g * NACT + a]);
-                        if (ok[g] && lane == 0) s_maxq[ie[g]] = mx;
+                            for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
+                            s_maxq[il] = mx;
+                        }
                     }
                     SCG_GROUP_END
                 }
@@ -542,16 +546,20 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     const v2f w2 = {wj, wj};                              // op_sel splat of a pair half
                     qa = __builtin_elementwise_fma(w2, pa, qa);
                     qb = __builtin_elementwise_fma(w2, pb, qb);)
-                float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
-                wave_sum_n<GI>(qs);
+                const float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
+                float qo[1];
+                quad_transposed_sum<1>(qs, qo, lane);                 // lane l holds Q(s,a) of item (l & 3)
                 float dl[GI];
-#pragma unroll
-                for (int g = 0; g < GI; ++g) {
-                    const int i = ie[g];
+                {
+                    const int gl = lane & 3;
+                    const int i = gl == 0 ? ie[0] : gl == 1 ? ie[1] : gl == 2 ? ie[2] : ie[3];
                     const float r = (k == 0) ? s_r0[i] : s_ro[i];
                     const float cont = (k == 0) ? s_c0[i] : s_co[i];
                     const float target = cont > 0.0f ? fmaf(cont, s_maxq[i], r) : r;
-                    dl[g] = ok[g] ? target - qs[g] : 0.0f;            // padding item: += 0
+                    const float d = target - qo[0];
+#pragma unroll
+                    for (int g = 0; g < GI; ++g)                       // lanes 0..3 -> wave-uniform; padding item: += 0
+                        dl[g] = ok[g] ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), g)) : 0.0f;
                 }
                 ccx = cmx_; ccy = cmy_;
                 SCG_SLOT_LOOP4(
@@ -611,6 +619,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 #undef SCG_GROUP_END
 #undef SCG_R
 #undef SCG_R_SET
+#undef SCG_R4
 }
 
 // ------------------------------------------------------------------------------------------------
