@@ -249,7 +249,7 @@ typedef struct {
 
 static void block_vf_pass(const float *Wk, int n_items, const td_item *items, const env_rec *rec,
                           const float *phi_s, const float *phi_n, float *qcache, int qstride,
-                          int env0, float *Pout, int *n_upd) {
+                          const int *env_of, float *Pout, int *n_upd) {
     /* acc[wave][a][f]. Evaluations first (order-free: each item's Q values depend on nothing else). */
     float *acc = (float *)calloc((size_t)SCO_WAVES * NACT * NF, sizeof(float));
     float *maxq = (float *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(float));
@@ -261,7 +261,7 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
             const float *pn = phi_n + (size_t)it->env * NF;
             for (int a = 0; a < NACT; ++a) qn[a] = wave_dot(Wk + a * NF, pn);
             if (it->cache)
-                for (int a = 0; a < NACT; ++a) qcache[(size_t)a * qstride + env0 + it->env] = qn[a];
+                for (int a = 0; a < NACT; ++a) qcache[(size_t)a * qstride + env_of[it->env]] = qn[a];
             float m = qn[0];
             for (int a = 1; a < NACT; ++a) m = fmaxf(m, qn[a]);
             maxq[i] = m;
@@ -339,7 +339,7 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
             if (items[i].tgt)
                 state_features(rec[i].sn[0], rec[i].sn[1], rec[i].sn[2], rec[i].sn[3], phi_n + (size_t)i * NF);
         }
-        block_vf_pass(Wk, nb, items, rec, phi_s, phi_n, dummy_q, 0, 0, P + (size_t)b * NACT * NF, &cnts[b]);
+        block_vf_pass(Wk, nb, items, rec, phi_s, phi_n, dummy_q, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b]);
         free(rec); free(items); free(phi_s); free(phi_n);
     }
     int total = 0;
@@ -369,6 +369,17 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
     const int N = p->n_envs;
     const int n_vf = p->n_options + 1;
     const int nblk = (N + SCO_BLOCK_ENVS - 1) / SCO_BLOCK_ENVS;
+    /* SPEC §5: envs are taken in the order of (option_id at entry, env index) — a stable counting sort —
+     * and blocks are 256 consecutive positions of that order. Every per-env array stays indexed by env. */
+    int *perm = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+    {
+        int pos = 0;
+        for (int k = 0; k < n_vf; ++k)
+            for (int e = 0; e < N; ++e)
+                if (option_id[e] == k) perm[pos++] = e;
+        for (int e = 0; e < N; ++e)              /* ids outside [0, n_vf) (never produced by the step) go last */
+            if (option_id[e] < 0 || option_id[e] >= n_vf) perm[pos++] = e;
+    }
     float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * n_vf * NACT * NF);
     int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1) * n_vf, sizeof(int));
     int nthreads = p->n_threads > 0 ? p->n_threads : 1;
@@ -384,8 +395,10 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         float *phi_n = (float *)malloc(sizeof(float) * (size_t)nb * NF);
         td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
         /* ---- phase P: act, physics, bookkeeping, option logic (per env) */
+        int env_of[SCO_BLOCK_ENVS];
         for (int i = 0; i < nb; ++i) {
-            int e = e0 + i;
+            int e = perm[e0 + i];
+            env_of[i] = e;
             uint64_t g = (uint64_t)(p->env_id_base + e);
             uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(t & 0xffffffffu), (uint32_t)(t >> 32), 0u};
             uint32_t key[2] = {(uint32_t)(p->seed & 0xffffffffu), (uint32_t)(p->seed >> 32)};
@@ -459,7 +472,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 items[m].cont = cont;
                 ++m;
             }
-            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, phi_s, phi_n, qcache, N, e0,
+            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, phi_s, phi_n, qcache, N, env_of,
                           P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k]);
         }
         free(phi_s); free(phi_n); free(items);
@@ -471,7 +484,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         for (int b = 0; b < nblk; ++b) tot += cnts[(size_t)b * n_vf + k];
         n_k[k] = tot;
     }
-    free(P); free(cnts);
+    free(P); free(cnts); free(perm);
 }
 
 /* ------------------------------------------------------------------ SPEC §6: logistic regression */

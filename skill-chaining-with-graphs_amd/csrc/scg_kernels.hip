@@ -38,7 +38,8 @@ constexpr int OFF_ELIST = OFF_BUF + BUF_BYTES;                 // uint16 eval li
 constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[256] (5 action runs)
 constexpr int OFF_DELTA = OFF_ULIST + BLOCK_ENVS * 2;          // float delta[256] (per env)
 constexpr int OFF_MAXQ = OFF_DELTA + BLOCK_ENVS * 4;           // float maxq[256] (per env)
-constexpr int OFF_MISC = OFF_MAXQ + BLOCK_ENVS * 4;            // int misc[32]
+constexpr int OFF_ENV = OFF_MAXQ + BLOCK_ENVS * 4;             // int env[256]: env index of each block slot
+constexpr int OFF_MISC = OFF_ENV + BLOCK_ENVS * 4;             // int misc[32]
 constexpr int LDS_BYTES = OFF_MISC + 128;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_POW % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
@@ -75,6 +76,7 @@ struct StepArgs {
     const float *clf;              // [n_vf][8]
     const float *edges;            // device [n_edges][8]
     const uint64_t *cellmask;      // device [32*32][4] candidate-edge masks per grid cell
+    const int32_t *perm;           // FUSED: envs in (option_id, env) order (SPEC §5); NULL = identity
     const float *starts;           // device [n_starts][2]
     float *slabs;                  // [nblk][n_vf][5][1296]
     int32_t *cnts;                 // [nblk][n_vf]
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
     float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
     float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
+    int *s_env = reinterpret_cast<int *>(smem + OFF_ENV);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -131,13 +134,16 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 
     if (MODE == MODE_FUSED) {
         for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
+        if (tid == 0) s_misc[31] = 1;                      // bit k: some env of this workgroup has an item for VF k
         __syncthreads();
     }
 
     if (MODE == MODE_FUSED && A.diag == 1) return;
     // ------------------------------------------------------------------ phase P
     if (lane < 32) {                                  // 8 waves x 32 lanes: two waves per SIMD hide LDS latency
-        const int i = wave * 32 + lane, e = e0 + i;
+        const int i = wave * 32 + lane;
+        const int e = (MODE == MODE_FUSED && A.perm && i < nb) ? A.perm[e0 + i] : e0 + i;
+        s_env[i] = e;
         if (i < nb) {
             if (MODE == MODE_FUSED) {
                 // act (SPEC §2, §4.3)
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     }
                 }
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
+                atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
                 A.action[e] = (uint8_t)a; A.reward[e] = rew; A.done[e] = (uint8_t)dn;
                 A.x[e] = nx; A.y[e] = ny; A.vx[e] = nvx; A.vy[e] = nvy;
@@ -357,7 +364,12 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     _Pragma("unroll") for (int g = 0; g < GI; ++g) { ie[g] = ne[g]; ok[g] = nok[g]; }                   \
     ++par;
 
+    const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[31]) : ~0u;
     for (int k = A.k_lo; k <= A.k_hi; ++k) {
+        if (!((present >> k) & 1u)) {                      // nobody here runs or enters option k: skip the pass outright
+            if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = 0;
+            continue;
+        }
         __syncthreads();
         // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 256 envs:
         //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), env order
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         if (lane < GI && okl) {
                             if (s_on[il] == k) {
 #pragma unroll
-                                for (int a = 0; a < NACT; ++a) A.qcache[(size_t)a * N + e0 + il] = qo[a];
+                                for (int a = 0; a < NACT; ++a) A.qcache[(size_t)a * N + s_env[il]] = qo[a];
                             }
                             float mx = qo[0];
 #pragma unroll
@@ -727,6 +739,80 @@ __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// SPEC §5 env order: stable counting sort of the envs by option_id (6 keys), two tiny kernels per step.
+// Option-homogeneous workgroups turn five sparse option passes per workgroup into about one dense one.
+__global__ __launch_bounds__(256) void sort_hist_kernel(const int32_t *option_id, int n, int n_vf, int32_t *hist) {
+    __shared__ int s_c[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.x * 256 + tid;
+    int o = e < n ? option_id[e] : -1;
+    if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;          // out-of-range ids sort last (key n_vf <= 6)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uint64_t m = __ballot(o == k);
+        if (lane == 0) s_c[wave][k] = __popcll(m);
+    }
+    __syncthreads();
+    if (tid < 7) hist[blockIdx.x * 8 + tid] = s_c[0][tid] + s_c[1][tid] + s_c[2][tid] + s_c[3][tid];
+}
+
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option_id, int n, int n_vf, int nblk,
+                                                           const int32_t *hist, int32_t *perm) {
+    __shared__ int s_c[4][8];
+    __shared__ int s_off[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    // offset of (key k, block b) in the sorted order = (all envs with a smaller key) + (key-k envs of earlier blocks)
+    __shared__ int s_tot[8], s_pre[8], s_part[4][16];
+    int tot[7], pre[7];
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) { tot[kk] = 0; pre[kk] = 0; }
+    for (int bb0 = 0; bb0 < nblk; bb0 += 256) {
+        const int bb = bb0 + tid;
+        if (bb < nblk) {
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                const int h = hist[bb * 8 + kk];
+                tot[kk] += h;
+                if (bb < b) pre[kk] += h;
+            }
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) {                       // integer sums: any order
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { tot[kk] += __shfl_xor(tot[kk], m, 64); pre[kk] += __shfl_xor(pre[kk], m, 64); }
+        if (lane == 0) { s_part[wave][kk] = tot[kk]; s_part[wave][8 + kk] = pre[kk]; }
+    }
+    __syncthreads();
+    if (tid < 7) {
+        s_tot[tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+        s_pre[tid] = s_part[0][8 + tid] + s_part[1][8 + tid] + s_part[2][8 + tid] + s_part[3][8 + tid];
+    }
+    __syncthreads();
+    if (tid < 7) {
+        int before = 0;
+        for (int kk = 0; kk < tid; ++kk) before += s_tot[kk];
+        s_off[tid] = before + s_pre[tid];
+    }
+    const int e = b * 256 + tid;
+    int o = e < n ? option_id[e] : -1;
+    if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uint64_t m = __ballot(o == k);
+        if (lane == 0) s_c[wave][k] = __popcll(m);
+        if (o == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (o >= 0) {
+        int pos = s_off[o] + rank;
+        for (int w = 0; w < wave; ++w) pos += s_c[w][o];
+        perm[pos] = e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // un-fused kernels
 __global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y, float *vx, float *vy,
                                                       const uint8_t *action, float *reward, uint8_t *goal,
@@ -820,6 +906,7 @@ struct scg_ctx {
     MapScalars ms;
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
+    int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step
     unsigned long long *d_stamps;   // diagnostic build only (NULL otherwise)
     float *d_slabs;
     int32_t *d_cnts;
@@ -900,6 +987,8 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_nk, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_edges, MAX_EDGES * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_cellmask, (size_t)CELL_G * CELL_G * 4 * sizeof(uint64_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_G, 0, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
@@ -929,7 +1018,7 @@ int scg_destroy(scg_ctx *c) {
     if (!c) return SCG_OK;
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
     (void)hipFree(c->d_segs); (void)hipFree(c->d_segcnt);
-    (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask);
+    (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -1037,6 +1126,12 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     A.enabled = enabled_mask; A.learn = (flags & SCG_STEP_LEARN) ? 1u : 0u; A.t = t;
     if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
     A.diag = (flags >> 12) & 0xfu;       // diagnostic only: early exits for phase timing
+    // env order of this step (SPEC §5): counting sort by the option ids the previous step left
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(c->nblk), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->d_hist);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(c->nblk), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->nblk,
+                       c->d_hist, c->d_perm);
+    SCG_HIP(c, hipGetLastError());
+    A.perm = c->d_perm;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof_on) {
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
