@@ -210,8 +210,18 @@ __device__ __forceinline__ float pinball_step(const float *edges, const uint64_t
     const int cxi = min(max((int)(x * (float)CELL_G), 0), CELL_G - 1);
     const int cyi = min(max((int)(y * (float)CELL_G), 0), CELL_G - 1);
     const uint64_t *cm = cellmask + (size_t)(cyi * CELL_G + cxi) * 4;
-    uint64_t cand[NW];
-    bool any = false;
+    // Refine the cell mask exactly and keep the first KC survivors IN REGISTERS (edge index ascending, so
+    // "first intercepted edge" keeps its meaning); the 20 sub-steps then run without LDS round trips.
+    // Lanes with more than KC candidates (corners of dense maps) keep the rest in `over` and fall back
+    // to the LDS loop for those.
+    constexpr int KC = 3;
+    float cx0[KC], cy0[KC], cex[KC], cey[KC], cinv[KC];
+    int cidx[KC];
+    int nc = 0;
+    uint64_t over[NW];
+#pragma unroll
+    for (int q = 0; q < KC; ++q) { cx0[q] = 0.0f; cy0[q] = 0.0f; cex[q] = 0.0f; cey[q] = 0.0f; cinv[q] = 0.0f; cidx[q] = -1; }
+    bool any_over = false;
 #pragma unroll
     for (int g = 0; g < NW; ++g) {
         uint64_t m = cm[g], out = 0;
@@ -219,11 +229,23 @@ __device__ __forceinline__ float pinball_step(const float *edges, const uint64_t
             const int b = __builtin_ctzll(m);
             m &= m - 1;
             const int j = g * 64 + b;
-            if (edge_d2(E4[2 * j], edges[8 * j + 4], x, y) <= reach2) out |= (1ull << b);
+            const float4 ea = E4[2 * j];
+            const float inv = edges[8 * j + 4];
+            if (edge_d2(ea, inv, x, y) <= reach2) {
+                if (nc < KC) {
+#pragma unroll
+                    for (int q = 0; q < KC; ++q)
+                        if (q == nc) { cx0[q] = ea.x; cy0[q] = ea.y; cex[q] = ea.z; cey[q] = ea.w; cinv[q] = inv; cidx[q] = j; }
+                    ++nc;
+                } else {
+                    out |= (1ull << b);
+                }
+            }
         }
-        cand[g] = out;
-        any = any || (out != 0);
+        over[g] = out;
+        any_over = any_over || (out != 0);
     }
+    const bool any = nc > 0;
     // the goal disc can only be entered if it starts within reach as well
     const float gx0 = x - ms.TX, gy0 = y - ms.TY;
     const float gr = ms.TR + (rr - 1.0f) * ms.R;                       // TR + 1.10 |v| R + 2 % R
@@ -231,34 +253,47 @@ __device__ __forceinline__ float pinball_step(const float *edges, const uint64_t
     bool goal = false;
     const float h = ms.hstep;
     const bool wave_any = __ballot(any) != 0;             // wave-uniform: nobody near an edge -> free flight
+    const bool wave_over = __ballot(any_over) != 0;
     const bool wave_goal = __ballot(near_goal) != 0;
+    bool wslot[KC];
+#pragma unroll
+    for (int q = 0; q < KC; ++q) wslot[q] = __ballot(nc > q) != 0;
     for (int i = 0; i < 20; ++i) {
         x = fmaf(vx, h, x); y = fmaf(vy, h, y);
         int nhit = 0, first = -1;
         if (wave_any) {
 #pragma unroll
-            for (int g = 0; g < NW; ++g) {
-                uint64_t m = cand[g];
-                while (m) {
-                    const int j = g * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float4 ea = E4[2 * j];
-                    const float inv = edges[8 * j + 4];
-                    if (intercept(ea, inv, ms.R2, x, y, vx, vy)) {
-                        if (nhit == 0) first = j;
-                        ++nhit;
+            for (int q = 0; q < KC; ++q) {
+                if (wslot[q]) {
+                    const bool hit = (nc > q) && intercept(make_float4(cx0[q], cy0[q], cex[q], cey[q]), cinv[q], ms.R2, x, y, vx, vy);
+                    if (hit) { if (nhit == 0) first = cidx[q]; ++nhit; }
+                }
+            }
+            if (wave_over) {
+#pragma unroll
+                for (int g = 0; g < NW; ++g) {
+                    uint64_t m = over[g];
+                    while (m) {
+                        const int j = g * 64 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (intercept(E4[2 * j], edges[8 * j + 4], ms.R2, x, y, vx, vy)) {
+                            if (nhit == 0) first = j;
+                            ++nhit;
+                        }
                     }
                 }
             }
-            if (nhit == 1) {
-                const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
-                const float pr = fmaf(vy, uy, vx * ux);
-                const float tp = pr + pr;
-                const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
-                vx = nvx; vy = nvy;
-                if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
-            } else if (nhit > 1) {
-                vx = -vx; vy = -vy;
+            if (__ballot(nhit > 0)) {
+                if (nhit == 1) {
+                    const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
+                    const float pr = fmaf(vy, uy, vx * ux);
+                    const float tp = pr + pr;
+                    const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
+                    vx = nvx; vy = nvy;
+                    if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
+                } else if (nhit > 1) {
+                    vx = -vx; vy = -vy;
+                }
             }
         }
         if (wave_goal) {

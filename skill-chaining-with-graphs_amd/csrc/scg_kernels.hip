@@ -39,7 +39,8 @@ constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update 
 constexpr int OFF_DELTA = OFF_ULIST + BLOCK_ENVS * 2;          // float delta[256] (per env)
 constexpr int OFF_MAXQ = OFF_DELTA + BLOCK_ENVS * 4;           // float maxq[256] (per env)
 constexpr int OFF_ENV = OFF_MAXQ + BLOCK_ENVS * 4;             // int env[256]: env index of each block slot
-constexpr int OFF_MISC = OFF_ENV + BLOCK_ENVS * 4;             // int misc[32]
+constexpr int OFF_CLF = OFF_ENV + BLOCK_ENVS * 4;              // float clf[6][8]
+constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[32]
 constexpr int LDS_BYTES = OFF_MISC + 128;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_POW % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
     float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
     int *s_env = reinterpret_cast<int *>(smem + OFF_ENV);
+    float *s_clf = reinterpret_cast<float *>(smem + OFF_CLF);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     if (MODE == MODE_FUSED) {
         for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
         if (tid == 0) s_misc[31] = 1;                      // bit k: some env of this workgroup has an item for VF k
+        if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
         __syncthreads();
     }
 
@@ -181,28 +184,31 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 }
                 s_s[4 * BLOCK_ENVS + i] = nx; s_s[5 * BLOCK_ENVS + i] = ny;
                 s_s[6 * BLOCK_ENVS + i] = nvx; s_s[7 * BLOCK_ENVS + i] = nvy;
-                // options (SPEC §4.2)
+                // options (SPEC §4.2), branch-free: membership bit masks of s' and s_next over all options
+                // (classifier rows come from LDS), then the success / failure / selection rules on the masks
+                unsigned inA = 0, inB = 0;            // bit k: in_k(s'), in_k(s_next)
+#pragma unroll
+                for (int k = 1; k < MAX_VF; ++k) {
+                    if (k < A.n_vf && ((A.enabled >> k) & 1u)) {
+                        const float *w = s_clf + CLF_STRIDE * k;
+                        if (clf_z(w, sx, sy) > 0.0f) inA |= 1u << k;
+                        if (clf_z(w, nx, ny) > 0.0f) inB |= 1u << k;
+                    }
+                }
                 bool keep = false;
                 float ro = 0.0f, co = 0.0f;
                 if (o >= 1) {
-                    const bool succ = (o == 1) ? goal : in_set(A, o - 1, sx, sy);
-                    const bool fail = !succ && !in_set(A, o, sx, sy);
+                    const bool succ = (o == 1) ? goal : ((inA >> ((o - 1) & 31)) & 1u);
+                    const bool fail = !succ && !((inA >> (o & 31)) & 1u);
                     const bool otime = osteps + 1 >= A.max_opt;
                     const bool term = (dn != 0) || succ || fail || otime;
                     ro = rew + (succ ? A.r_succ : 0.0f);
                     co = term ? 0.0f : A.gamma;
                     keep = !term;
                 }
-                int on = 0;
-                if (keep) on = o;
-                else {
-                    for (int k = 1; k < A.n_vf; ++k) {
-                        if (!in_set(A, k, nx, ny)) continue;
-                        if (k >= 2 && in_set(A, k - 1, nx, ny)) continue;
-                        on = k;
-                        break;
-                    }
-                }
+                // smallest k with in_k(s_next) and (k == 1 or not in_(k-1)(s_next)); bit 0 of inB is never set
+                const unsigned sel = inB & ~(inB << 1);
+                const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
                 atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
