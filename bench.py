@@ -57,6 +57,20 @@ def flops_per_item(evaluated: bool, updated: bool) -> float:
     return f
 
 
+def measured_traffic(envs_per_gpu, n_options):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate passes; profiles/r01_traffic.json) — only when it was taken on this exact workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if w["envs_per_gpu"] == envs_per_gpu and w["n_options"] == n_options and w["map"] == MAP:
+            return t["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(seconds_target=15.0):
     """Time the CPU oracle on a bounded sample of the same workload (same map, options, hyper-params)."""
     import numpy as np
@@ -192,7 +206,7 @@ def main():
                        "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP},
             "roofline": {"bound": "hbm", "kernel": "td_kernel<MODE_FUSED>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kern_ms, "launches": int(k_n.value),
+                         "traffic": measured_traffic(n_local, n_opt), "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                          "note": "the fused kernel is fp32-VALU-bound, not HBM-bound (SURVEY.md §8d, DESIGN.md): "
                                  "see `valu` for the binding roofline"},
