@@ -712,10 +712,18 @@ __global__ __launch_bounds__(RED_THREADS) void reduce2_kernel(const ReduceArgs R
     float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 *p = reinterpret_cast<const float4 *>(R.segs) + (size_t)k * (NACT * NF / 4) + i4;
     const size_t stride4 = (size_t)R.n_vf * NACT * NF / 4;
-    for (int sg = 0; sg < nseg; ++sg) {
-        if (R.segcnt[(size_t)sg * R.n_vf + k] > 0) {
-            const float4 t = p[(size_t)sg * stride4];
-            S.x = S.x + t.x; S.y = S.y + t.y; S.z = S.z + t.z; S.w = S.w + t.w;
+    for (int s0 = 0; s0 < nseg; s0 += SEG) {               // 16 segment sums in flight, added in segment order
+        float4 t[SEG];
+        bool on[SEG];
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            on[u] = s0 + u < nseg && R.segcnt[(size_t)(s0 + u) * R.n_vf + k] > 0;     // wave-uniform
+            t[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (on[u]) t[u] = p[(size_t)(s0 + u) * stride4];
+        }
+#pragma unroll
+        for (int u = 0; u < SEG; ++u) {
+            if (on[u]) { S.x = S.x + t[u].x; S.y = S.y + t[u].y; S.z = S.z + t[u].z; S.w = S.w + t[u].w; }
         }
     }
     reinterpret_cast<float4 *>(R.G)[(size_t)k * (NACT * NF / 4) + i4] = S;
