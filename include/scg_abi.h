@@ -121,6 +121,21 @@ int scg_classifier_predict(scg_ctx *ctx, int32_t n, const float *x, const float 
 int scg_fit_initiation(scg_ctx *ctx, int32_t n_fit, const float *xy, const uint8_t *label,
                        const int32_t *offsets, float *w, int32_t iters, float lr, float l2, void *stream);
 
+/* ---- outer-loop support (SPEC §7): device-resident trajectory ring + per-step events,
+ * so that the host skill-discovery loop never has to read env state every step.
+ * scg_set_trace_buffers: caller-owned device buffers filled by every following scg_step (NULLs disable):
+ *   ring_x, ring_y  f32[ring_len][N]  position of s_t at row (ep_steps at entry) & (ring_len-1); ring_len = 2^m
+ *   events          u8[N]   bit 0 = reached the goal this step; bit k (1..5) = s' lies in initiation set k
+ *   ev_len          i32[N]  states recorded so far in the env's episode (ep_steps at entry + 1)
+ * scg_harvest: for each listed env (device int32 list, caller-sorted) emit L_pos + L_neg examples taken
+ * backwards from the most recent recorded state: out_xy[n_sel][L][2], out_label[n_sel][L] u8 with
+ * 1 = one of the last L_pos states, 0 = older, 255 = no such state (episode too short / ring overwritten). */
+int scg_set_trace_buffers(scg_ctx *ctx, float *ring_x, float *ring_y, int32_t ring_len, uint8_t *events,
+                          int32_t *ev_len);
+int scg_harvest(scg_ctx *ctx, int32_t n_sel, const int32_t *sel_env, const float *ring_x, const float *ring_y,
+                int32_t ring_len, const int32_t *ev_len, int32_t l_pos, int32_t l_neg, float *out_xy,
+                uint8_t *out_label, void *stream);
+
 /* ---- measurement hooks (bench.py's roofline leg) ----
  * scg_profile_reset(ctx, 1) makes every following scg_step record a HIP event pair round its fused
  * kernel on the launch stream; scg_profile_read synchronises those events and returns the summed

@@ -449,6 +449,18 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 }
             o_t[i] = o; o_n[i] = on;
             r0[i] = rew; c0[i] = dn ? 0.0f : p->gamma;
+            /* SPEC §7: trajectory ring (position of s_t) and per-step events */
+            if (p->ring_x) {
+                size_t row = (size_t)(ep_steps[e] & (p->ring_len - 1)) * N + e;
+                p->ring_x[row] = rec[i].s[0]; p->ring_y[row] = rec[i].s[1];
+            }
+            if (p->events) {
+                unsigned inA = 0;
+                for (int k = 1; k <= p->n_options; ++k)
+                    if (in_set(p, clf, k, sx, sy)) inA |= 1u << k;
+                p->events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu));
+                p->ev_len[e] = eps1;
+            }
             /* outputs */
             action[e] = (uint8_t)a; reward[e] = rew; done[e] = (uint8_t)dn;
             x[e] = nx; y[e] = ny; vx[e] = nvx; vy[e] = nvy;
@@ -485,6 +497,27 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         n_k[k] = tot;
     }
     free(P); free(cnts); free(perm);
+}
+
+/* ------------------------------------------------------------------ SPEC §7: example harvest */
+void sco_harvest(int n_sel, const int32_t *sel_env, const float *ring_x, const float *ring_y, int ring_len,
+                 int n_envs, const int32_t *ev_len, int l_pos, int l_neg, float *out_xy, uint8_t *out_label) {
+    const int L = l_pos + l_neg;
+    for (int si = 0; si < n_sel; ++si) {
+        int e = sel_env[si];
+        for (int j = 0; j < L; ++j) {
+            size_t t = (size_t)si * L + j;
+            int idx = ev_len[e] - 1 - j;
+            int ok = idx >= 0 && j < ring_len;
+            float x = 0.0f, y = 0.0f;
+            if (ok) {
+                size_t row = (size_t)(idx & (ring_len - 1)) * n_envs + e;
+                x = ring_x[row]; y = ring_y[row];
+            }
+            out_xy[2 * t] = x; out_xy[2 * t + 1] = y;
+            out_label[t] = ok ? (j < l_pos ? 1 : 0) : 255;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ SPEC §6: logistic regression */

@@ -38,6 +38,11 @@ typedef struct {
     const float *starts;        /* [n_starts][2] */
     float radius, hstep, r2, tx, ty, tr2;
     const float *scale;         /* [1296] 1/||c|| */
+    /* SPEC §7 trace buffers (NULL = off) */
+    float *ring_x, *ring_y;     /* [ring_len][n_envs] */
+    uint8_t *events;            /* [n_envs] */
+    int32_t *ev_len;            /* [n_envs] */
+    int32_t ring_len;           /* power of two */
 } sco_params;
 
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -64,6 +69,9 @@ void sco_apply(const sco_params *p, int n_vf, float *W, const float *G, const in
 void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int32_t *option_id,
               int32_t *opt_steps, int32_t *ep_steps, float *qcache, uint8_t *action, float *reward,
               uint8_t *done, const float *W, const float *clf, uint64_t t, float *G, int32_t *n_k);
+/* SPEC §7: examples from the trajectory ring for the listed envs: out_xy[n_sel][L][2], out_label[n_sel][L] */
+void sco_harvest(int n_sel, const int32_t *sel_env, const float *ring_x, const float *ring_y, int ring_len,
+                 int n_envs, const int32_t *ev_len, int l_pos, int l_neg, float *out_xy, uint8_t *out_label);
 /* SPEC §6: n_fit problems; offsets[n_fit+1] index xy/label; w[n_fit][8] in/out. */
 void sco_fit_initiation(int n_fit, const float *xy, const uint8_t *label, const int32_t *offsets,
                         float *w, int iters, float lr, float l2);

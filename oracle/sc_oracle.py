@@ -26,6 +26,8 @@ class Params(C.Structure):
         ("radius", C.c_float), ("hstep", C.c_float), ("r2", C.c_float),
         ("tx", C.c_float), ("ty", C.c_float), ("tr2", C.c_float),
         ("scale", C.c_void_p),
+        ("ring_x", C.c_void_p), ("ring_y", C.c_void_p), ("events", C.c_void_p), ("ev_len", C.c_void_p),
+        ("ring_len", C.c_int32),
     ]
 
 
@@ -147,6 +149,23 @@ class Oracle:
                         _p(st["action"]), _p(st["reward"]), _p(st["done"]), _p(W), _p(_f32(clf)),
                         C.c_uint64(t), _p(G), _p(n_k))
         return G, n_k
+
+    def set_trace(self, ring_len):
+        """SPEC §7: allocate + attach trace buffers (ring_x, ring_y [ring_len, N], events [N], ev_len [N])."""
+        n = self.p.n_envs
+        self.ring_x = np.zeros((ring_len, n), np.float32); self.ring_y = np.zeros((ring_len, n), np.float32)
+        self.events = np.zeros(n, np.uint8); self.ev_len = np.zeros(n, np.int32)
+        self.p.ring_x = self.ring_x.ctypes.data; self.p.ring_y = self.ring_y.ctypes.data
+        self.p.events = self.events.ctypes.data; self.p.ev_len = self.ev_len.ctypes.data
+        self.p.ring_len = ring_len
+
+    def harvest(self, sel_env, l_pos, l_neg):
+        sel = np.ascontiguousarray(sel_env, np.int32)
+        L = l_pos + l_neg
+        xy = np.zeros((len(sel), L, 2), np.float32); lab = np.zeros((len(sel), L), np.uint8)
+        self.L.sco_harvest(len(sel), _p(sel), _p(self.ring_x), _p(self.ring_y), self.p.ring_len, self.p.n_envs,
+                           _p(self.ev_len), l_pos, l_neg, _p(xy), _p(lab))
+        return xy, lab
 
     def fit_initiation(self, xy, label, offsets, w, iters, lr, l2):
         offsets = np.ascontiguousarray(offsets, np.int32)

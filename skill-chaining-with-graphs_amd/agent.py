@@ -40,6 +40,38 @@ class SkillChainingAgent:
             raise ValueError("option index out of range")
         self.enabled_mask = (self.enabled_mask | (1 << k)) if enabled else (self.enabled_mask & ~(1 << k))
 
+    # ------------------------------------------------------------------ skill discovery (outer loop, SPEC §7)
+    def enable_tracing(self, ring_len: int = 256) -> None:
+        """Attach the device-resident trajectory ring + per-step event flags (costs ~13 B/env-step)."""
+        self.trace = self.ctx.set_trace_buffers(ring_len)
+        self._examples = {}
+
+    def collect_examples(self, k: int, l_pos: int = 32, l_neg: int = 32, max_envs: int = 4096) -> int:
+        """Call after a step_batch while option k is being created: envs whose step ended inside option k's
+        target region (goal disc for k = 1, initiation set k-1 otherwise) contribute their last l_pos
+        ring states as positives and the l_neg states before those as negatives. Returns #examples held."""
+        ring_x, ring_y, events, ev_len = self.trace
+        bit = 1 if k == 1 else (1 << (k - 1))
+        sel = torch.nonzero(events & bit).flatten().to(torch.int32)[:max_envs]       # ascending env ids
+        if sel.numel():
+            xy, lab = self.ctx.harvest(sel.contiguous(), l_pos, l_neg)
+            keep = lab.view(-1) != 255
+            xy, lab = xy.view(-1, 2)[keep], lab.view(-1)[keep]
+            px, pl = self._examples.get(k, (xy[:0], lab[:0]))
+            self._examples[k] = (torch.cat([px, xy]), torch.cat([pl, lab]))
+        return int(self._examples.get(k, (torch.empty(0),))[0].shape[0])
+
+    def create_option(self, k: int, iters: int = 400, lr: float = 3.0, l2: float = 1e-4) -> float:
+        """Fit initiation classifier k on the collected examples (GPU logistic regression), start its value
+        function from the root's, enable it. Returns the training accuracy."""
+        xy, lab = self._examples[k]
+        clf = self.options[k].initiation_classifier
+        clf.fit(xy.contiguous(), lab.contiguous(), iters=iters, lr=lr, l2=l2)
+        self.W[k].copy_(self.W[0])
+        self.enable_option(k)
+        pred = clf.predict(xy[:, 0].contiguous(), xy[:, 1].contiguous())
+        return float((pred == lab).float().mean())
+
     def init_weights(self, std: float = 1e-3, seed: int = 0) -> None:
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.W.copy_(torch.randn(self.W.shape, generator=g) * std)

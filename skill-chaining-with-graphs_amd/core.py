@@ -110,6 +110,43 @@ class ScgContext:
                    _ptr(st.done), _ptr(W), _ptr(clf), C.c_uint32(enabled_mask), C.c_uint64(t),
                    C.c_uint32(flags), self._stream())
 
+    # ------------------------------------------------------------------ outer-loop support (SPEC §7)
+    def set_trace_buffers(self, ring_len: int):
+        """Allocate and attach the trajectory ring + event buffers; returns (ring_x, ring_y, events, ev_len).
+        ring_len must be a power of two; ring_len = 0 detaches."""
+        if ring_len == 0:
+            self._call("scg_set_trace_buffers", None, None, 0, None, None)
+            self._trace = None
+            return None
+        if ring_len < 1 or ring_len & (ring_len - 1):
+            raise ScgError("ring_len must be a power of two")
+        N = self.n_envs
+        ring_x = torch.zeros((ring_len, N), dtype=torch.float32, device=self.device)
+        ring_y = torch.zeros((ring_len, N), dtype=torch.float32, device=self.device)
+        events = torch.zeros(N, dtype=torch.uint8, device=self.device)
+        ev_len = torch.zeros(N, dtype=torch.int32, device=self.device)
+        self._call("scg_set_trace_buffers", _ptr(ring_x), _ptr(ring_y), ring_len, _ptr(events), _ptr(ev_len))
+        self._trace = (ring_x, ring_y, events, ev_len)
+        return self._trace
+
+    def harvest(self, sel_env: torch.Tensor, l_pos: int, l_neg: int):
+        """Examples for the listed envs (int32, device) from the ring: (xy[n,L,2] f32, label[n,L] u8)."""
+        if getattr(self, "_trace", None) is None:
+            raise ScgError("harvest: trace buffers are not attached (set_trace_buffers)")
+        ring_x, ring_y, _, ev_len = self._trace
+        n = sel_env.numel()
+        self._chk(sel_env, torch.int32, n, "sel_env")
+        if n and (int(sel_env.min()) < 0 or int(sel_env.max()) >= self.n_envs):
+            raise ScgError("harvest: env index out of range")
+        L = l_pos + l_neg
+        if l_pos < 0 or l_neg < 0 or L < 1:
+            raise ScgError("harvest: need l_pos + l_neg >= 1")
+        xy = torch.zeros((n, L, 2), dtype=torch.float32, device=self.device)
+        lab = torch.zeros((n, L), dtype=torch.uint8, device=self.device)
+        self._call("scg_harvest", n, _ptr(sel_env), _ptr(ring_x), _ptr(ring_y), ring_x.shape[0], _ptr(ev_len),
+                   l_pos, l_neg, _ptr(xy), _ptr(lab), self._stream())
+        return xy, lab
+
     def grad_buffers(self):
         """(G[n_vf,5,1296] float32, n_k[n_vf] int32): caller-owned torch tensors that scg_step(LEARN)
         fills with the rank-local gradient sum and update counts (the all-reduce operands, SPEC §5)."""

@@ -78,6 +78,10 @@ struct StepArgs {
     const float *edges;            // device [n_edges][8]
     const uint64_t *cellmask;      // device [32*32][4] candidate-edge masks per grid cell
     const int32_t *perm;           // FUSED: envs in (option_id, env) order (SPEC §5); NULL = identity
+    float *ring_x, *ring_y;        // SPEC §7 trace buffers (NULL = off)
+    uint8_t *events;
+    int32_t *ev_len;
+    int32_t ring_mask;             // ring_len - 1
     const float *starts;           // device [n_starts][2]
     float *slabs;                  // [nblk][n_vf][5][1296]
     int32_t *cnts;                 // [nblk][n_vf]
@@ -213,6 +217,11 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
                 A.action[e] = (uint8_t)a; A.reward[e] = rew; A.done[e] = (uint8_t)dn;
+                if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
+                    const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
+                    A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
+                }
+                if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
                 A.x[e] = nx; A.y[e] = ny; A.vx[e] = nvx; A.vy[e] = nvy;
                 A.option_id[e] = on;
                 A.opt_steps[e] = keep ? osteps + 1 : 0;
@@ -827,6 +836,27 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
 }
 
 // ------------------------------------------------------------------------------------------------
+// SPEC §7: examples for an initiation-set fit, gathered from the trajectory ring (one thread per example)
+__global__ __launch_bounds__(256) void harvest_kernel(int n_sel, const int32_t *sel_env, const float *ring_x,
+                                                      const float *ring_y, int ring_len, int n, const int32_t *ev_len,
+                                                      int l_pos, int l_neg, float *out_xy, uint8_t *out_label) {
+    const int L = l_pos + l_neg;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n_sel * L) return;
+    const int si = (int)(t / L), j = (int)(t - (long long)si * L);       // j = age: 0 = most recent recorded state
+    const int e = sel_env[si];
+    const int idx = ev_len[e] - 1 - j;
+    const bool ok = idx >= 0 && j < ring_len;
+    float x = 0.0f, y = 0.0f;
+    if (ok) {
+        const size_t row = (size_t)(idx & (ring_len - 1)) * n + e;
+        x = ring_x[row]; y = ring_y[row];
+    }
+    out_xy[2 * t] = x; out_xy[2 * t + 1] = y;
+    out_label[t] = ok ? (j < l_pos ? 1 : 0) : 255;
+}
+
+// ------------------------------------------------------------------------------------------------
 // un-fused kernels
 __global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y, float *vx, float *vy,
                                                       const uint8_t *action, float *reward, uint8_t *goal,
@@ -921,6 +951,10 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step
+    float *ring_x, *ring_y;        // SPEC §7 caller-owned trace buffers (NULL = off)
+    uint8_t *events;
+    int32_t *ev_len;
+    int32_t ring_len;
     unsigned long long *d_stamps;   // diagnostic build only (NULL otherwise)
     float *d_slabs;
     int32_t *d_cnts;
@@ -1102,6 +1136,8 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.ms = c->ms;
     A.edges = c->d_edges; A.starts = c->d_starts; A.cellmask = c->d_cellmask;
     A.slabs = c->d_slabs; A.cnts = c->d_cnts;
+    A.ring_x = c->ring_x; A.ring_y = c->ring_y; A.events = c->events; A.ev_len = c->ev_len;
+    A.ring_mask = c->ring_len > 0 ? c->ring_len - 1 : 0;
     A.stamps = c->d_stamps;
 }
 
@@ -1173,6 +1209,32 @@ extern "C" int scg_diag_stamps(scg_ctx *c, unsigned long long *host_out /*[nblk]
     return SCG_OK;
 }
 #endif
+
+int scg_set_trace_buffers(scg_ctx *c, float *ring_x, float *ring_y, int32_t ring_len, uint8_t *events,
+                          int32_t *ev_len) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_trace_buffers: null ctx");
+    if ((ring_x == nullptr) != (ring_y == nullptr)) return fail(c, SCG_ERR_INVALID, "scg_set_trace_buffers: ring_x and ring_y go together");
+    if (ring_x && (ring_len < 1 || (ring_len & (ring_len - 1)))) return fail(c, SCG_ERR_INVALID, "scg_set_trace_buffers: ring_len must be a power of two");
+    if ((events == nullptr) != (ev_len == nullptr)) return fail(c, SCG_ERR_INVALID, "scg_set_trace_buffers: events and ev_len go together");
+    c->ring_x = ring_x; c->ring_y = ring_y; c->ring_len = ring_x ? ring_len : 0; c->events = events; c->ev_len = ev_len;
+    return SCG_OK;
+}
+
+int scg_harvest(scg_ctx *c, int32_t n_sel, const int32_t *sel_env, const float *ring_x, const float *ring_y,
+                int32_t ring_len, const int32_t *ev_len, int32_t l_pos, int32_t l_neg, float *out_xy,
+                uint8_t *out_label, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_harvest: null ctx");
+    if (n_sel < 0 || l_pos < 0 || l_neg < 0 || l_pos + l_neg < 1 || ring_len < 1 || (ring_len & (ring_len - 1)) ||
+        !sel_env || !ring_x || !ring_y || !ev_len || !out_xy || !out_label)
+        return fail(c, SCG_ERR_INVALID, "scg_harvest: bad argument");
+    if (n_sel == 0) return SCG_OK;
+    const long long total = (long long)n_sel * (l_pos + l_neg);
+    hipLaunchKernelGGL(harvest_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), n_sel, sel_env, ring_x, ring_y, ring_len, c->cfg.n_envs,
+                       ev_len, l_pos, l_neg, out_xy, out_label);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
 
 int scg_profile_reset(scg_ctx *c, int32_t enable) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_profile_reset: null ctx");
