@@ -33,8 +33,6 @@ extern "C" {
 #define SCG_MAX_OPTIONS 5
 #define SCG_MAX_EDGES 256
 #define SCG_CLF_STRIDE 8           /* floats per classifier row (6 used) */
-#define SCG_BLOCK_ENVS 256         /* SPEC §5 reduction geometry */
-#define SCG_WAVES 8
 
 typedef enum {
     SCG_OK = 0,
@@ -62,6 +60,7 @@ typedef struct {
 #define SCG_STEP_APPLY 2u        /* apply it to W in the same call (single-rank path) */
 
 int scg_abi_version(void);
+int scg_block_envs(void);            /* SPEC §5 geometry this library was built with: 256 (8 waves) or 128 (4 waves) */
 const char *scg_strerror(int status);
 const char *scg_last_error(const scg_ctx *ctx);
 

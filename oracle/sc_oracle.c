@@ -15,6 +15,9 @@
 #endif
 
 #define NACT SCO_NACT
+/* SPEC §5 geometry: envs per block and wavefronts per block (256/8 by default; 128/4 is the other build) */
+static int g_block_envs = SCO_BLOCK_ENVS, g_waves = SCO_WAVES;
+void sco_set_geometry(int block_envs, int waves) { g_block_envs = block_envs; g_waves = waves; }
 #define NF SCO_NF
 #define NLANE 64
 #define NSLOT 21
@@ -251,7 +254,7 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
                           const float *phi_s, const float *phi_n, float *qcache, int qstride,
                           const int *env_of, float *Pout, int *n_upd) {
     /* acc[wave][a][f]. Evaluations first (order-free: each item's Q values depend on nothing else). */
-    float *acc = (float *)calloc((size_t)SCO_WAVES * NACT * NF, sizeof(float));
+    float *acc = (float *)calloc((size_t)g_waves * NACT * NF, sizeof(float));
     float *maxq = (float *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(float));
     int cnt = 0;
     for (int i = 0; i < n_items; ++i) {
@@ -275,7 +278,7 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
             const td_item *it = &items[i];
             const env_rec *r = &rec[it->env];
             if (!it->upd || r->a != act) continue;
-            int w = (q + in_run / 4) % SCO_WAVES;
+            int w = (q + in_run / 4) % g_waves;
             const float *ps = phi_s + (size_t)it->env * NF;
             float qsa = wave_dot(Wk + r->a * NF, ps);
             float target = it->tgt ? fmaf(it->cont, maxq[i], it->r) : it->r;
@@ -289,7 +292,7 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
     free(maxq);
     for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
         float s = acc[i];
-        for (int w = 1; w < SCO_WAVES; ++w) s = s + acc[(size_t)w * NACT * NF + i];
+        for (int w = 1; w < g_waves; ++w) s = s + acc[(size_t)w * NACT * NF + i];
         Pout[i] = s;
     }
     free(acc);
@@ -315,15 +318,15 @@ static float seg_sum(const float *P, size_t stride, size_t idx, int nblk) {
 int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint8_t *action,
                       const float *r, const float *cont, const float *sn4[4], const float *Wk, float *G) {
     init_order();
-    int nblk = (n + SCO_BLOCK_ENVS - 1) / SCO_BLOCK_ENVS;
+    int nblk = (n + g_block_envs - 1) / g_block_envs;
     float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * NACT * NF);
     int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1), sizeof(int));
     int nthreads = p && p->n_threads > 0 ? p->n_threads : 1;
     (void)nthreads;
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
     for (int b = 0; b < nblk; ++b) {
-        int e0 = b * SCO_BLOCK_ENVS;
-        int nb = n - e0 < SCO_BLOCK_ENVS ? n - e0 : SCO_BLOCK_ENVS;
+        int e0 = b * g_block_envs;
+        int nb = n - e0 < g_block_envs ? n - e0 : g_block_envs;
         env_rec *rec = (env_rec *)malloc(sizeof(env_rec) * nb);
         td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
         float *phi_s = (float *)malloc(sizeof(float) * (size_t)nb * NF);
@@ -368,7 +371,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
     init_order();
     const int N = p->n_envs;
     const int n_vf = p->n_options + 1;
-    const int nblk = (N + SCO_BLOCK_ENVS - 1) / SCO_BLOCK_ENVS;
+    const int nblk = (N + g_block_envs - 1) / g_block_envs;
     /* SPEC §5: envs are taken in the order of (option_id at entry, env index) — a stable counting sort —
      * and blocks are 256 consecutive positions of that order. Every per-env array stays indexed by env. */
     int *perm = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
@@ -386,8 +389,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
     (void)nthreads;
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
     for (int b = 0; b < nblk; ++b) {
-        int e0 = b * SCO_BLOCK_ENVS;
-        int nb = N - e0 < SCO_BLOCK_ENVS ? N - e0 : SCO_BLOCK_ENVS;
+        int e0 = b * g_block_envs;
+        int nb = N - e0 < g_block_envs ? N - e0 : g_block_envs;
         env_rec rec[SCO_BLOCK_ENVS];
         int o_t[SCO_BLOCK_ENVS], o_n[SCO_BLOCK_ENVS];
         float r0[SCO_BLOCK_ENVS], c0[SCO_BLOCK_ENVS], ro[SCO_BLOCK_ENVS], co[SCO_BLOCK_ENVS];

@@ -45,6 +45,7 @@ typedef struct {
     int32_t ring_len;           /* power of two */
 } sco_params;
 
+void sco_set_geometry(int block_envs, int waves);   /* SPEC §5 geometry of the build under test */
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void sco_sincospi(float t, float *c, float *s);
 float sco_sigmoid(float z);

@@ -50,6 +50,12 @@ def lib() -> C.CDLL:
         _lib.sco_sigmoid.argtypes = [C.c_float]
         _lib.sco_feature_index.restype = C.c_int
         _lib.sco_q_update_grad.restype = C.c_int
+        try:      # follow the geometry of the HIP library under test (SPEC §5), if it has been built
+            import skill_chaining_with_graphs_amd as _scg
+            be = _scg.load_library().scg_block_envs()
+            _lib.sco_set_geometry(be, be // 32)
+        except Exception:
+            pass
     return _lib
 
 

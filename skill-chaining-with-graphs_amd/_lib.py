@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libscg_hip.so")
+LIB_PATH = os.environ.get("SCG_LIB") or os.path.join(_HERE, "csrc", "libscg_hip.so")   # SCG_LIB: A/B builds
 
 NUM_ACTIONS = 5
 FOURIER_ORDER = 5
@@ -45,6 +45,7 @@ class ScgConfig(C.Structure):
 _P = C.c_void_p
 _SIGS = {
     "scg_abi_version": (C.c_int, []),
+    "scg_block_envs": (C.c_int, []),
     "scg_strerror": (C.c_char_p, [C.c_int]),
     "scg_last_error": (C.c_char_p, [_P]),
     "scg_create": (C.c_int, [C.POINTER(_P), C.POINTER(ScgConfig)]),

@@ -11,8 +11,12 @@ namespace scg {
 constexpr int NACT = 5;
 constexpr int NF = 1296;
 constexpr int NSLOT = 21;          // feature slots per lane (SPEC §3.1)
-constexpr int BLOCK_ENVS = 256;    // SPEC §5 geometry
-constexpr int WAVES = 8;
+#ifndef SCG_BLOCK_ENVS
+#define SCG_BLOCK_ENVS 256
+#endif
+constexpr int BLOCK_ENVS = SCG_BLOCK_ENVS;    // SPEC §5 geometry: envs per workgroup (256 or 128)
+constexpr int WAVES = BLOCK_ENVS / 32;        // 32 envs per wavefront in phase P
+constexpr int LIST_WAVES = BLOCK_ENVS / 64;   // waves that ballot the workgroup's env flags
 constexpr int THREADS = WAVES * 64;
 constexpr int MAX_EDGES = 256;
 constexpr int CLF_STRIDE = 8;

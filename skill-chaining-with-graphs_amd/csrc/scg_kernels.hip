@@ -30,10 +30,12 @@ constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro
 constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [256] (+pad)
 constexpr int OFF_POW = OFF_INT + 4 * BLOCK_ENVS;              // float2 pow[256][2][20]
 constexpr int TAB_FLOATS = 72 * 8;                             // one table buffer: 72 entries x {x[4], y[4]}
-constexpr int SCR_BYTES = WAVES * 2 * TAB_FLOATS * 4;          // per wave two table buffers (36 KB)
+constexpr int SCR_WAVE_FLOATS = 2 * TAB_FLOATS > 15 * 64 ? 2 * TAB_FLOATS : 15 * 64;   // table buffers / reduction parking
+constexpr int SCR_BYTES = WAVES * SCR_WAVE_FLOATS * 4;         // per wave two table buffers (36 KB at 8 waves)
 constexpr int POW_N = 21;                                      // Z_d^1..5 for d = 0..3, then (1,0)
 constexpr int OFF_BUF = OFF_POW + BLOCK_ENVS * 2 * POW_N * 8;  // float buf[5*1296] ALIASES the table scratch
-constexpr int BUF_BYTES = SCR_BYTES > NACT * NF * 4 ? SCR_BYTES : NACT * NF * 4;
+constexpr bool STAGE_W_LDS = BLOCK_ENVS >= 256;                // 128-env workgroups fetch W_k straight into registers
+constexpr int BUF_BYTES = (!STAGE_W_LDS || SCR_BYTES > NACT * NF * 4) ? SCR_BYTES : NACT * NF * 4;
 constexpr int OFF_ELIST = OFF_BUF + BUF_BYTES;                 // uint16 eval list[256]
 constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[256] (5 action runs)
 constexpr int OFF_DELTA = OFF_ULIST + BLOCK_ENVS * 2;          // float delta[256] (per env)
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     SCG_STAMP(0);   // phase P
     // ------------------------------------------------------------------ phase Z (SPEC §3)
     {
-        const int i = tid & (BLOCK_ENVS - 1), sg = tid >> 8;
+        const int i = tid & (BLOCK_ENVS - 1), sg = tid / BLOCK_ENVS;
         if (i < nb && (MODE != MODE_QVAL || sg == 1)) {
             const float *st = s_s + sg * 4 * BLOCK_ENVS;
             state_powers(st[i], st[BLOCK_ENVS + i], st[2 * BLOCK_ENVS + i], st[3 * BLOCK_ENVS + i],
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     const float m20 = v20 ? 1.0f : 0.0f;
 
     // scratch tables: per wave 2 buffers x 72 entries (AB 0..35, CD 36..71) x {x[4 items], y[4 items]}
-    float *scr0 = s_scr + wave * (2 * TAB_FLOATS);
+    float *scr0 = s_scr + wave * SCR_WAVE_FLOATS;
     const float4 *t_m0 = reinterpret_cast<const float4 *>(scr0) + 2 * hi;                    // [4j], [4j+1]
     const float4 *t_t0 = reinterpret_cast<const float4 *>(scr0) + 2 * tl;                    // [32t], [32t+1]
     const float4 *t_t20 = reinterpret_cast<const float4 *>(scr0) + 2 * min(32 + tl, 35);
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             at = s_a[tid];
         }
         uint64_t mb[1 + NACT];
-        if (wave < 4) {
+        if (wave < LIST_WAVES) {
             mb[0] = __ballot(ev);
 #pragma unroll
             for (int a = 0; a < NACT; ++a) mb[1 + a] = __ballot(up && at == a);
@@ -415,18 +417,24 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         __syncthreads();
         int n_ev = 0, run_len[NACT], run_off[NACT], qbase[NACT + 1];
         {
-            n_ev = __builtin_amdgcn_readfirstlane(s_misc[0] + s_misc[8] + s_misc[16] + s_misc[24]);
+            int se = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < LIST_WAVES; ++w2) se += s_misc[w2 * 8];
+            n_ev = __builtin_amdgcn_readfirstlane(se);
             int off = 0, qb = 0;
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {      // wave-uniform: keep them in SGPRs (16 VGPRs otherwise)
-                run_len[a] = __builtin_amdgcn_readfirstlane(s_misc[1 + a] + s_misc[9 + a] + s_misc[17 + a] + s_misc[25 + a]);
+                int sr = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < LIST_WAVES; ++w2) sr += s_misc[w2 * 8 + 1 + a];
+                run_len[a] = __builtin_amdgcn_readfirstlane(sr);
                 run_off[a] = off; qbase[a] = qb;
                 off += run_len[a]; qb += (run_len[a] + 3) >> 2;
             }
             qbase[NACT] = qb;
         }
         const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
-        if (wave < 4) {
+        if (wave < LIST_WAVES) {
             const uint64_t below = (1ull << lane) - 1ull;
             if (ev) {
                 int off = 0;
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 
         // W_k -> LDS once per workgroup (coalesced float4; the staging area is the reduction buffer, idle
         // here) -> each lane's 105 weights -> registers. Eight waves no longer fetch the same 26 KB each.
-        {
+        if constexpr (STAGE_W_LDS) {
             const float4 *Wk4 = reinterpret_cast<const float4 *>(A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF));
             float4 *b4 = reinterpret_cast<float4 *>(s_buf);
             for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) b4[f4] = Wk4[f4];
@@ -464,8 +472,24 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 }
             }
             __syncthreads();                                       // the staging area becomes table scratch
+        } else {
+            // 128-env workgroups (two per CU): no LDS room for the 26 KB staging area — every wave fetches its
+            // 105 weights per lane through the buffer descriptor (L2-resident)
+            const uint32_t kb = (MODE == MODE_QVAL) ? 0u : (uint32_t)k * (NACT * NF * 4);
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+                for (int j = 0; j < 18; ++j)
+                    SCG_R_SET(a, j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                        w_rsrc, w_vm, kb + (uint32_t)(a * NF + 72 * j) * 4u, 0)));
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        w_rsrc, (t < 2 || v20) ? w_vt : 0u, kb + (uint32_t)(a * NF + 576 * t) * 4u, 0));
+                    SCG_R_SET(a, 18 + t, (t < 2 || v20) ? v : 0.0f);
+                }
+            }
         }
-
         SCG_STAMP(k == 0 ? 2 : 9);    // W staging
         // ---- loop A (W_k live): Q_k(s_next, .) of one quad at a time -> qcache, max -> s_maxq[env]
         {
@@ -608,7 +632,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         // 37k cycles per pass, a third of the kernel.)
         {
             float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
-            float *park = s_scr + wave * (15 * 64) + lane;             // [wave][15][64]
+            float *park = s_scr + wave * SCR_WAVE_FLOATS + lane;       // [wave][15][64]
 #pragma unroll
             for (int c = 0; c < NSLOT / 3; ++c) {
                 __syncthreads();                                       // scratch free (tables / previous chunk)
@@ -623,7 +647,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     const int a = v15 / 3, j = 3 * c + (v15 - 3 * a);
                     float sum = s_scr[o];
 #pragma unroll
-                    for (int w = 1; w < WAVES; ++w) sum = sum + s_scr[w * (15 * 64) + o];
+                    for (int w = 1; w < WAVES; ++w) sum = sum + s_scr[w * SCR_WAVE_FLOATS + o];
                     // canonical feature index of (lane l, slot j) — SPEC §3.1
                     int f = -1;
                     if (j < 18) f = (2 * j + (l >> 5)) * 36 + (l & 31);
@@ -990,6 +1014,8 @@ extern "C" {
 
 int scg_abi_version(void) { return SCG_ABI_VERSION; }
 
+int scg_block_envs(void) { return BLOCK_ENVS; }
+
 const char *scg_strerror(int status) {
     switch (status) {
         case SCG_OK: return "ok";
@@ -1177,8 +1203,9 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
     A.diag = (flags >> 12) & 0xfu;       // diagnostic only: early exits for phase timing
     // env order of this step (SPEC §5): counting sort by the option ids the previous step left
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(c->nblk), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->d_hist);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(c->nblk), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->nblk,
+    const int nrow = (c->cfg.n_envs + 255) / 256;        // the sort works on rows of 256 envs whatever the workgroup size
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->d_hist);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, nrow,
                        c->d_hist, c->d_perm);
     SCG_HIP(c, hipGetLastError());
     A.perm = c->d_perm;

@@ -32,6 +32,27 @@ def test_pinball_step_bit_exact(map_name):
             assert g_o[:64].all() and 0 < g_o.sum() < n
 
 
+def test_pinball_step_dense_map_four_mask_words_bit_exact():
+    """160 edges (> 128: four 64-bit candidate words) and tight corridors (lanes with > 3 candidates)."""
+    import sc_oracle
+    from skill_chaining_with_graphs_amd.core import ScgContext
+    from util import HP, SCALE, dense_map
+    m = dense_map()
+    assert m.n_edges > 128
+    n = 30000
+    ctx = ScgContext(n, 0, m, **HP)
+    orc = sc_oracle.Oracle(m, SCALE, n_envs=n, **HP)
+    x, y, vx, vy = random_states(m, n, 21, vmax=2.8)
+    act = np.random.default_rng(22).integers(0, 5, n).astype(np.uint8)
+    d = [dev(a) for a in (x, y, vx, vy)]
+    for it in range(5):
+        r_o, g_o = orc.pinball_step(x, y, vx, vy, act)
+        r_d, g_d = ctx.pinball_step(d, dev(act))
+        for name, a, b in zip("x y vx vy".split(), d, (x, y, vx, vy)):
+            assert np.array_equal(a.cpu().numpy(), b), (it, name)
+        assert np.array_equal(r_d.cpu().numpy(), r_o) and np.array_equal(g_d.cpu().numpy(), g_o)
+
+
 def test_features_and_q_values_bit_exact():
     n = 3000                                                  # 12 blocks, last one ragged
     ctx, orc, m = make_pair("pinball_simple", n)

@@ -54,3 +54,16 @@ def fourier_reference(x, y, vx, vy):
     idx = np.arange(1296)
     c = np.stack([(idx // 6 ** (3 - d)) % 6 for d in range(4)], 1).astype(np.float64)
     return np.cos(np.pi * s @ c.T)
+
+
+def dense_map(n_side=6, size=0.035):
+    """A synthetic map with many small square obstacles (16 + 4 n_side^2 edges): exercises the 4-word candidate
+    masks (> 128 edges) and lanes with more than three candidate edges (overflow path of the HIP physics)."""
+    lines = ["ball 0.015", "target 0.93 0.07 0.03", "start 0.07 0.93",
+             "polygon 0.0 0.0 0.0 0.01 1.0 0.01 1.0 0.0", "polygon 0.0 0.0 0.01 0.0 0.01 1.0 0.0 1.0",
+             "polygon 0.0 1.0 0.0 0.99 1.0 0.99 1.0 1.0", "polygon 1.0 1.0 0.99 1.0 0.99 0.0 1.0 0.0"]
+    for i in range(n_side):
+        for j in range(n_side):
+            cx, cy = 0.16 + 0.136 * i, 0.16 + 0.136 * j
+            lines.append(f"polygon {cx - size} {cy - size} {cx + size} {cy - size} {cx + size} {cy + size} {cx - size} {cy + size}")
+    return scg.parse_map("\n".join(lines), "dense_synthetic")
