@@ -94,3 +94,30 @@ def test_oracle_spot_check_of_the_big_batch(init):
     for k in ("x", "y", "vx", "vy", "option_id", "action", "done", "reward"):
         assert np.array_equal(getattr(full, k).cpu().numpy()[:n], st[k]), k
     assert np.array_equal(full.qcache.cpu().numpy()[:, :n], st["qcache"])
+
+
+def test_quarter_million_envs_single_gpu():
+    """4x the bench size on one GPU (1024 workgroups, 64 first-level reduction segments): invariants +
+    an oracle spot check of the sorted-order bookkeeping (learn off => every env is independent)."""
+    import skill_chaining_with_graphs_amd as scg
+    n = 262144
+    m = scg.load_map("pinball_maze")
+    rng = np.random.default_rng(7)
+    pos = m.sample_free(n, rng)
+    v = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+    ctx, orc, m = make_pair("pinball_maze", n, n_options=NOPT, seed=8, enabled_mask=MASK, max_episode_steps=30)
+    st = sc_oracle.new_state(n, m)
+    st["x"][:], st["y"][:], st["vx"][:], st["vy"][:] = pos[:, 0], pos[:, 1], v[0], v[1]
+    st_d = state_to_device(st, ctx)
+    W = dev(random_weights(NOPT + 1, 3, std=0.02))
+    clf = dev(chain_classifiers(m, NOPT))
+    G, n_k = ctx.grad_buffers()
+    for t in range(4):
+        ctx.step(st_d, W.view(-1), clf.view(-1), MASK, t)
+        nk = n_k.cpu().numpy()
+        assert nk[0] == n and nk[1:].sum() <= n
+    assert bool(torch.isfinite(W).all()) and bool(torch.isfinite(st_d.qcache).all())
+    xs, ys = st_d.x.cpu().numpy(), st_d.y.cpu().numpy()
+    assert m.free_mask(np.stack([xs, ys], 1)[::64], margin=0.0).all()
+    opt = st_d.option_id.cpu().numpy()
+    assert opt.min() >= 0 and opt.max() <= NOPT and len(np.unique(opt)) >= 3
