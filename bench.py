@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--options", type=int, default=N_OPTIONS)
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = CPU-side rehearsal of the N>1 path on a 1-GPU box (every rank computes on cuda:0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learn", action="store_true", help="diagnostic: act + physics + qcache only")
     ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
@@ -132,11 +134,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0                      # all ranks share the one card; gloo carries the (tiny) collectives
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_local = args.envs_per_gpu
     n_opt = args.options
@@ -183,7 +191,7 @@ def main():
     lib.scg_profile_read(ctx, C.byref(k_ms), C.byref(k_n))
     lib.scg_profile_reset(ctx, 0)
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())

@@ -85,8 +85,13 @@ class SkillChainingAgent:
         self.ctx.step(self.state, self.W, self.clf, self.enabled_mask, self.t, learn=learn, apply=not shared)
         if shared:
             import torch.distributed as dist
-            dist.all_reduce(G, group=self.group)       # RCCL over xGMI: one fused 26 KB x n_vf message
-            dist.all_reduce(n_k, group=self.group)
+            if dist.get_backend(self.group) == "gloo":  # CPU rehearsal of the N>1 path: stage through the host
+                Gc, nc = G.cpu(), n_k.cpu()
+                dist.all_reduce(Gc, group=self.group); dist.all_reduce(nc, group=self.group)
+                G.copy_(Gc); n_k.copy_(nc)
+            else:
+                dist.all_reduce(G, group=self.group)    # RCCL over xGMI: one fused 26 KB x n_vf message
+                dist.all_reduce(n_k, group=self.group)
             self.ctx.apply_update(self.W, G, n_k)
         self.t += 1
 

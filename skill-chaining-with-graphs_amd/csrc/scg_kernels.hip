@@ -1,14 +1,16 @@
 // scg_kernels.hip — gfx950 kernels + the C-ABI of include/scg_abi.h.
 //
-// Layout of one step-batch (SPEC §5): a workgroup = 8 wavefronts owns 256 consecutive envs.
-//   phase P  (one lane per env)      act from qcache, Pinball physics with the edge table in LDS,
-//                                    reset/bookkeeping, option termination + selection
+// One step-batch (SPEC §5) = sort_hist + sort_scatter (env order) -> td_kernel<FUSED> -> reduce1 -> reduce2.
+// td_kernel: a workgroup = 8 wavefronts owns 256 consecutive positions of the option-sorted env order.
+//   phase P  (one lane per env)       act from qcache, Pinball physics (cell mask -> exact refine -> up to
+//                                     three candidate edges in registers), reset/bookkeeping, option logic
 //   phase Z  (one lane per env-state) unit-complex powers Z_d^k of s and s_next -> LDS
-//   phase TD (one lane per 21 features, one item per wave at a time), VF by VF:
-//            W_k and the gradient accumulator live in registers (2 x 105 VGPRs);
-//            Q(s_next,.) / Q(s,a) by fma chains + a 64-lane butterfly; per-wave accumulators are
-//            summed in wave order through LDS and stored as the block's partial slab
-//   reduce   slabs -> G (block order), n_k, W += alpha/n_k * scale * G
+//   phase TD (one lane per 21 features, four items per wave-iteration), value function by value function:
+//            lists by ballot -> loop A: Q_k(s_next,.) with W_k in 105 VGPRs, packed-fp32 FMAs, transposed
+//            butterflies -> loop BC per action run: Q_k(s,a) -> TD error -> accumulate (one W row + the
+//            105-VGPR accumulator) -> chunked cross-wave reduction through LDS -> the block's slab
+//   reduce1/2  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G
+// Every sum has the pinned order of SPEC §3.1 / §5 (no atomics on data): the CPU oracle reproduces every bit.
 // No upstream code exists to cite (reference = README.md:1-2); sections cite SPEC.md.
 #include "scg_device.hpp"
 #include "../../include/scg_abi.h"
@@ -38,8 +40,7 @@ constexpr bool STAGE_W_LDS = BLOCK_ENVS >= 256;                // 128-env workgr
 constexpr int BUF_BYTES = (!STAGE_W_LDS || SCR_BYTES > NACT * NF * 4) ? SCR_BYTES : NACT * NF * 4;
 constexpr int OFF_ELIST = OFF_BUF + BUF_BYTES;                 // uint16 eval list[256]
 constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[256] (5 action runs)
-constexpr int OFF_DELTA = OFF_ULIST + BLOCK_ENVS * 2;          // float delta[256] (per env)
-constexpr int OFF_MAXQ = OFF_DELTA + BLOCK_ENVS * 4;           // float maxq[256] (per env)
+constexpr int OFF_MAXQ = OFF_ULIST + BLOCK_ENVS * 2;           // float maxq[256] (per env)
 constexpr int OFF_ENV = OFF_MAXQ + BLOCK_ENVS * 4;             // int env[256]: env index of each block slot
 constexpr int OFF_CLF = OFF_ENV + BLOCK_ENVS * 4;              // float clf[6][8]
 constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[32]
@@ -125,7 +126,6 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     float *s_buf = reinterpret_cast<float *>(smem + OFF_BUF);
     uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
     uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
-    float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
     float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
     int *s_env = reinterpret_cast<int *>(smem + OFF_ENV);
     float *s_clf = reinterpret_cast<float *>(smem + OFF_CLF);
