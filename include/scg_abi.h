@@ -120,6 +120,11 @@ int scg_classifier_predict(scg_ctx *ctx, int32_t n, const float *x, const float 
 int scg_fit_initiation(scg_ctx *ctx, int32_t n_fit, const float *xy, const uint8_t *label,
                        const int32_t *offsets, float *w, int32_t iters, float lr, float l2, void *stream);
 
+/* Option graph (SPEC §4.2): parents[k] for k = 1..n_options (HOST int32[n_options+1], entry 0
+ * ignored) = the option whose initiation set option k targets, 0 = the task goal. Default: the chain
+ * k -> k-1. Must be acyclic (every option reaches the goal). */
+int scg_set_option_parents(scg_ctx *ctx, const int32_t *parents);
+
 /* ---- outer-loop support (SPEC §7): device-resident trajectory ring + per-step events,
  * so that the host skill-discovery loop never has to read env state every step.
  * scg_set_trace_buffers: caller-owned device buffers filled by every following scg_step (NULLs disable):

@@ -434,7 +434,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             int keep = 0;
             ro[i] = 0.0f; co[i] = 0.0f;
             if (o >= 1) {
-                int succ = (o == 1) ? goal : in_set(p, clf, o - 1, sx, sy);
+                int par = p->parents[o & 7];
+                int succ = (par == 0) ? goal : in_set(p, clf, par, sx, sy);
                 int fail = !succ && !in_set(p, clf, o, sx, sy);
                 int otime = opt_steps[e] + 1 >= p->max_option_steps;
                 int term = (dn != 0) || succ || fail || otime;
@@ -447,7 +448,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             else
                 for (int k = 1; k <= p->n_options; ++k) {
                     if (!in_set(p, clf, k, nx, ny)) continue;
-                    if (k >= 2 && in_set(p, clf, k - 1, nx, ny)) continue;
+                    if (p->parents[k] != 0 && in_set(p, clf, p->parents[k], nx, ny)) continue;
                     on = k; break;
                 }
             o_t[i] = o; o_n[i] = on;

@@ -43,6 +43,7 @@ typedef struct {
     uint8_t *events;            /* [n_envs] */
     int32_t *ev_len;            /* [n_envs] */
     int32_t ring_len;           /* power of two */
+    int32_t parents[8];         /* SPEC §4.2 option graph: target option of k (0 = goal); [0] unused */
 } sco_params;
 
 void sco_set_geometry(int block_envs, int waves);   /* SPEC §5 geometry of the build under test */

@@ -28,6 +28,7 @@ class Params(C.Structure):
         ("scale", C.c_void_p),
         ("ring_x", C.c_void_p), ("ring_y", C.c_void_p), ("events", C.c_void_p), ("ev_len", C.c_void_p),
         ("ring_len", C.c_int32),
+        ("parents", C.c_int32 * 8),
     ]
 
 
@@ -87,6 +88,7 @@ class Oracle:
                         radius=sc[0], hstep=sc[1], r2=sc[2], tx=sc[3], ty=sc[4], tr2=sc[5],
                         scale=self.scale.ctypes.data)
         self.n_vf = n_options + 1
+        self.set_parents(list(range(-1, 7)))            # default chain: 1 -> goal, k -> k-1
 
     # ---- primitives
     def philox(self, ctr, key):
@@ -155,6 +157,11 @@ class Oracle:
                         _p(st["action"]), _p(st["reward"]), _p(st["done"]), _p(W), _p(_f32(clf)),
                         C.c_uint64(t), _p(G), _p(n_k))
         return G, n_k
+
+    def set_parents(self, parents):
+        """SPEC §4.2 option graph: parents[k] = target option of k (0 = goal)."""
+        for k in range(8):
+            self.p.parents[k] = max(int(parents[k]), 0) if k < len(parents) else 0
 
     def set_trace(self, ring_len):
         """SPEC §7: allocate + attach trace buffers (ring_x, ring_y [ring_len, N], events [N], ev_len [N])."""

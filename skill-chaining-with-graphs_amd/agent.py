@@ -72,6 +72,24 @@ class SkillChainingAgent:
         pred = clf.predict(xy[:, 0].contiguous(), xy[:, 1].contiguous())
         return float((pred == lab).float().mean())
 
+    # ------------------------------------------------------------------ the skill graph (SPEC §4.2)
+    def set_option_parents(self, parents) -> None:
+        """parents[k] = the option whose initiation set option k chains to (0 = task goal); entry 0 ignored.
+        The default is a chain; any acyclic assignment gives a skill tree rooted at the goal."""
+        self.ctx.set_option_parents(parents)
+
+    def skill_graph(self):
+        """networkx.DiGraph of the discovered skills: node 0 = task goal, node k = option k (attrs: enabled,
+        classifier weights), edge k -> parent[k] = "executing k leads into the initiation set of parent"."""
+        import networkx as nx
+        g = nx.DiGraph()
+        g.add_node(0, kind="goal", target=tuple(self.map.target))
+        clf = self.clf.cpu().numpy()
+        for k in range(1, self.n_options + 1):
+            g.add_node(k, kind="option", enabled=bool((self.enabled_mask >> k) & 1), classifier=clf[k, :6].tolist())
+            g.add_edge(k, int(self.ctx.parents[k]))
+        return g
+
     def init_weights(self, std: float = 1e-3, seed: int = 0) -> None:
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.W.copy_(torch.randn(self.W.shape, generator=g) * std)

@@ -51,6 +51,7 @@ class ScgContext:
         self._ctx = C.c_void_p()
         _lib.check(self.lib.scg_create(C.byref(self._ctx), C.byref(self.cfg)), None, "scg_create")
         self.scale = fourier_scale_table()
+        self.parents = np.arange(-1, n_options, dtype=np.int32).clip(0)      # default chain k -> k-1
         edges, starts, sc = pmap.edges, np.ascontiguousarray(pmap.starts, np.float32), pmap.scalars
         self._call("scg_set_map", edges.ctypes.data_as(C.c_void_p), len(edges),
                    starts.ctypes.data_as(C.c_void_p), len(starts), sc.ctypes.data_as(C.c_void_p),
@@ -109,6 +110,15 @@ class ScgContext:
                    _ptr(st.opt_steps), _ptr(st.ep_steps), _ptr(st.qcache), _ptr(st.action), _ptr(st.reward),
                    _ptr(st.done), _ptr(W), _ptr(clf), C.c_uint32(enabled_mask), C.c_uint64(t),
                    C.c_uint32(flags), self._stream())
+
+    def set_option_parents(self, parents) -> None:
+        """SPEC §4.2 option graph: parents[k] (k = 1..n_options) = option whose initiation set option k targets,
+        0 = the task goal. Default is the chain k -> k-1. Validated (range, acyclic) by the library."""
+        arr = np.zeros(self.n_options + 1, np.int32)
+        arr[1:] = np.asarray(list(parents)[1:self.n_options + 1] if len(parents) > self.n_options
+                             else list(parents), np.int32)[: self.n_options]
+        self.parents = arr
+        self._call("scg_set_option_parents", arr.ctypes.data_as(C.c_void_p))
 
     # ------------------------------------------------------------------ outer-loop support (SPEC §7)
     def set_trace_buffers(self, ring_len: int):

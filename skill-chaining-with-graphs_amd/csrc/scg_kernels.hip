@@ -91,6 +91,7 @@ struct StepArgs {
     unsigned long long *stamps;    // diagnostic build only
     int32_t n, n_vf, k_lo, k_hi;
     uint32_t enabled, learn, diag;
+    uint32_t parents;              // 3 bits per option k at [3k, 3k+3): target option of k (0 = the task goal)
     uint64_t t, seed;
     int64_t env_base;
     float gamma, epsilon, r_succ;
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 bool keep = false;
                 float ro = 0.0f, co = 0.0f;
                 if (o >= 1) {
-                    const bool succ = (o == 1) ? goal : ((inA >> ((o - 1) & 31)) & 1u);
+                    const unsigned par = (A.parents >> (3 * (o & 7))) & 7u;       // SPEC §4.2: target of option o
+                    const bool succ = (par == 0) ? goal : ((inA >> par) & 1u);
                     const bool fail = !succ && !((inA >> (o & 31)) & 1u);
                     const bool otime = osteps + 1 >= A.max_opt;
                     const bool term = (dn != 0) || succ || fail || otime;
@@ -212,8 +214,14 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     co = term ? 0.0f : A.gamma;
                     keep = !term;
                 }
-                // smallest k with in_k(s_next) and (k == 1 or not in_(k-1)(s_next)); bit 0 of inB is never set
-                const unsigned sel = inB & ~(inB << 1);
+                // smallest k with in_k(s_next) and s_next outside k's target region
+                unsigned tgtB = 0;                    // bit k: s_next already lies in option k's target region
+#pragma unroll
+                for (int k = 1; k < MAX_VF; ++k) {
+                    const unsigned par = (A.parents >> (3 * k)) & 7u;
+                    if (par != 0 && ((inB >> par) & 1u)) tgtB |= 1u << k;
+                }
+                const unsigned sel = inB & ~tgtB;
                 const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
                 atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
@@ -975,6 +983,7 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step
+    uint32_t parents;              // packed option targets (default: the chain k -> k-1)
     float *ring_x, *ring_y;        // SPEC §7 caller-owned trace buffers (NULL = off)
     uint8_t *events;
     int32_t *ev_len;
@@ -1083,6 +1092,8 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
     if (hipMalloc(&c->d_stamps, (size_t)c->nblk * 16 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 16 * sizeof(unsigned long long));
 #endif
+    c->parents = 0;
+    for (int k = 1; k < MAX_VF; ++k) c->parents |= (uint32_t)(k - 1) << (3 * k);      // chain: 1 -> goal, k -> k-1
     c->G_out = c->d_G; c->nk_out = c->d_nk;
     *out = c;
     return SCG_OK;
@@ -1162,6 +1173,7 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.ms = c->ms;
     A.edges = c->d_edges; A.starts = c->d_starts; A.cellmask = c->d_cellmask;
     A.slabs = c->d_slabs; A.cnts = c->d_cnts;
+    A.parents = c->parents;
     A.ring_x = c->ring_x; A.ring_y = c->ring_y; A.events = c->events; A.ev_len = c->ev_len;
     A.ring_mask = c->ring_len > 0 ? c->ring_len - 1 : 0;
     A.stamps = c->d_stamps;
@@ -1236,6 +1248,23 @@ extern "C" int scg_diag_stamps(scg_ctx *c, unsigned long long *host_out /*[nblk]
     return SCG_OK;
 }
 #endif
+
+int scg_set_option_parents(scg_ctx *c, const int32_t *parents) {
+    if (!c || !parents) return fail(c, SCG_ERR_INVALID, "scg_set_option_parents: null argument");
+    uint32_t packed = 0;
+    for (int k = 1; k <= c->cfg.n_options; ++k) {
+        if (parents[k] < 0 || parents[k] > c->cfg.n_options || parents[k] == k)
+            return fail(c, SCG_ERR_INVALID, "scg_set_option_parents: parent must be 0 (goal) or another option");
+        packed |= (uint32_t)parents[k] << (3 * k);
+    }
+    for (int k = 1; k <= c->cfg.n_options; ++k) {          // no cycles: following parents must reach the goal
+        int p = k, hops = 0;
+        while (p != 0 && hops <= SCG_MAX_OPTIONS) { p = parents[p]; ++hops; }
+        if (p != 0) return fail(c, SCG_ERR_INVALID, "scg_set_option_parents: the option graph has a cycle");
+    }
+    c->parents = packed;
+    return SCG_OK;
+}
 
 int scg_set_trace_buffers(scg_ctx *c, float *ring_x, float *ring_y, int32_t ring_len, uint8_t *events,
                           int32_t *ev_len) {

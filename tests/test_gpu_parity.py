@@ -173,3 +173,45 @@ def test_host_checks_fail_before_any_launch():
         ctx.q_values((x, x, x, x), torch.zeros(10, device="cuda:0"))
     with pytest.raises(ScgError):
         ctx.features((x.cpu(), x, x, x))
+
+
+def test_skill_tree_rollout_bit_exact_and_graph_export():
+    """SPEC §4.2 option graph: a tree (1 -> goal, 2 -> goal, 3 -> 1, 4 -> 2, 5 -> 4) instead of the default chain."""
+    from util import disc_weights
+    from skill_chaining_with_graphs_amd import ScgError
+    n, n_options, mask, parents = 2000, 5, 0b111110, [0, 0, 0, 1, 2, 4]
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=n_options, seed=17, enabled_mask=mask)
+    ctx.set_option_parents(parents)
+    orc.set_parents(parents)
+    tx, ty, _ = m.target
+    clf = np.zeros((6, 8), np.float32)
+    for k, (cx, cy, r) in enumerate([(tx, ty, 0.15), (tx - 0.25, ty + 0.1, 0.15), (tx, ty + 0.3, 0.2),
+                                     (tx - 0.45, ty + 0.3, 0.2), (tx - 0.6, ty + 0.55, 0.25)], start=1):
+        clf[k] = disc_weights(cx, cy, r)
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 18, vmax=1.0)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    W_o = random_weights(6, 19, std=0.05)
+    st_d, W_d, clf_d = state_to_device(st_o, ctx), dev(W_o.copy()), dev(clf)
+    G_d, n_d = ctx.grad_buffers()
+    seen = set()
+    for t in range(10):
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        orc.apply(W_o, G, n_k)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), mask, t)
+        assert_state_equal(st_d, st_o, msg=f"t={t}")
+        assert np.array_equal(W_d.cpu().numpy(), W_o), t
+        seen |= set(np.unique(st_o["option_id"]).tolist())
+    assert {1, 2, 3, 4, 5} <= seen
+    for bad in ([0, 2, 1, 0, 0, 0], [0, 0, 0, 3, 0, 0], [0, 0, 0, 0, 0, 9]):      # 1<->2 cycle, self loop, out of range
+        with pytest.raises(ScgError):
+            ctx.set_option_parents(bad)
+
+
+def test_agent_skill_graph_export():
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    ag = SkillChainingAgent("pinball_simple", 256, 3)
+    ag.set_option_parents([0, 0, 1, 1])
+    ag.enable_option(1)
+    g = ag.skill_graph()
+    assert sorted(g.edges()) == [(1, 0), (2, 1), (3, 1)] and g.nodes[1]["enabled"] and not g.nodes[2]["enabled"]

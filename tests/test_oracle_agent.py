@@ -175,3 +175,25 @@ def test_fit_initiation_learns_a_disc():
         reg[0] = 0
         w64 -= 4.0 * (g + reg)
     assert np.allclose(w[0, :6], w64, rtol=2e-3, atol=2e-3)
+
+
+def test_skill_graph_parents_generalise_the_chain():
+    """SPEC §4.2 with a tree: options 1 and 2 both target the goal, option 3 targets option 2."""
+    orc, m = make_oracle("pinball_empty", n_envs=1, n_options=3, seed=0, epsilon=0.0, enabled_mask=0b1110)
+    orc.set_parents([0, 0, 0, 2])
+    clf = np.zeros((4, 8), np.float32)
+    clf[1] = disc_weights(0.8, 0.8, 0.12)            # I_1: small disc round the goal
+    clf[2] = disc_weights(0.6, 0.8, 0.12)            # I_2: a different region, also leads to the goal
+    clf[3] = disc_weights(0.35, 0.8, 0.15)           # I_3: leads into I_2
+    W = np.zeros((4, 5, 1296), np.float32)
+    st = sc_oracle.new_state(1, m)
+    st["x"][0], st["y"][0] = 0.35, 0.8
+    orc.step(st, W, clf, 0)
+    assert st["option_id"][0] == 3
+    st["x"][0], st["y"][0] = 0.58, 0.8               # inside I_2 = the target of option 3 -> success, 2 takes over
+    G, n_k = orc.step(st, W, clf, 1)
+    assert st["option_id"][0] == 2 and n_k.tolist() == [1, 0, 0, 1]
+    assert G[3, st["action"][0], 0] == pytest.approx(-5.0 + HP["r_option_success"])
+    st["x"][0], st["y"][0] = 0.8, 0.72               # inside I_1 only: not option 2's target (the goal is) -> 2 fails, 1 selected
+    G, n_k = orc.step(st, W, clf, 2)
+    assert st["option_id"][0] == 1 and G[2, st["action"][0], 0] == pytest.approx(-5.0)
