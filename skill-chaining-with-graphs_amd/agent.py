@@ -45,14 +45,22 @@ class SkillChainingAgent:
         """Attach the device-resident trajectory ring + per-step event flags (costs ~13 B/env-step)."""
         self.trace = self.ctx.set_trace_buffers(ring_len)
         self._examples = {}
+        self._prev_in = {}
 
     def collect_examples(self, k: int, l_pos: int = 32, l_neg: int = 32, max_envs: int = 4096) -> int:
         """Call after a step_batch while option k is being created: envs whose step ended inside option k's
-        target region (goal disc for k = 1, initiation set k-1 otherwise) contribute their last l_pos
-        ring states as positives and the l_neg states before those as negatives. Returns #examples held."""
+        target region (goal disc if parent[k] = 0, else the parent's initiation set, on the step they ENTER it)
+        contribute their last l_pos ring states as positives and the l_neg states before those as negatives.
+        Returns #examples held."""
         ring_x, ring_y, events, ev_len = self.trace
-        bit = 1 if k == 1 else (1 << (k - 1))
-        sel = torch.nonzero(events & bit).flatten().to(torch.int32)[:max_envs]       # ascending env ids
+        parent = int(self.ctx.parents[k])
+        bit = 1 if parent == 0 else (1 << parent)
+        hit = (events & bit) != 0
+        if parent:                                   # in-set bits stay up while the env is inside: keep entries only
+            prev = self._prev_in.get(k)
+            self._prev_in[k] = hit.clone()
+            hit = hit & ~prev if prev is not None else torch.zeros_like(hit)
+        sel = torch.nonzero(hit).flatten().to(torch.int32)[:max_envs]       # ascending env ids
         if sel.numel():
             xy, lab = self.ctx.harvest(sel.contiguous(), l_pos, l_neg)
             keep = lab.view(-1) != 255
@@ -71,6 +79,34 @@ class SkillChainingAgent:
         self.enable_option(k)
         pred = clf.predict(xy[:, 0].contiguous(), xy[:, 1].contiguous())
         return float((pred == lab).float().mean())
+
+    def chain_skills(self, steps_per_option: int = 300, min_examples: int = 2000, max_examples: int = 40000,
+                     l_pos: int = 24, l_neg: int = 24, start_coverage: float = 0.5, **fit) -> list:
+        """The outer loop of skill chaining (Konidaris & Barto 2009, the paper README.md:2 names), host-side
+        policy over the device-resident pieces: for each not-yet-enabled option k in index order, run
+        step-batches until enough trajectories have entered k's target (its parent in the skill graph),
+        fit initiation set k on them, enable the option, and stop once the start states are covered.
+        Returns one report dict per created option."""
+        report = []
+        sx = torch.as_tensor(self.map.starts[:, 0].copy(), device=self.W.device)
+        sy = torch.as_tensor(self.map.starts[:, 1].copy(), device=self.W.device)
+        for k in range(1, self.n_options + 1):
+            if (self.enabled_mask >> k) & 1:
+                continue
+            got = steps = 0
+            while steps < steps_per_option and got < max_examples:
+                self.step_batch()
+                got = self.collect_examples(k, l_pos, l_neg)
+                steps += 1
+            if got < min_examples:
+                break
+            acc = self.create_option(k, **fit)
+            cov = float(self.options[k].initiation_classifier.predict(sx, sy).float().mean())
+            report.append(dict(option=k, parent=int(self.ctx.parents[k]), steps=steps, examples=got,
+                               accuracy=acc, start_coverage=cov))
+            if cov >= start_coverage:
+                break
+        return report
 
     # ------------------------------------------------------------------ the skill graph (SPEC §4.2)
     def set_option_parents(self, parents) -> None:

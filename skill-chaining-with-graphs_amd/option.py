@@ -45,8 +45,8 @@ class InitiationClassifier:
 
 
 class Option:
-    """Option k of the chain: VF k (linear Q over the Fourier basis), initiation classifier k, target =
-    goal (k = 1) or initiation set of option k-1. k = 0 is the root policy."""
+    """Option k: VF k (linear Q over the Fourier basis), initiation classifier k, target = the task goal
+    (parent[k] = 0) or the initiation set of option parent[k] (default chain: k - 1). k = 0 is the root policy."""
 
     def __init__(self, agent: "SkillChainingAgent", index: int):  # noqa: F821
         self.agent, self.index = agent, index
@@ -83,6 +83,7 @@ class Option:
         g = goal.bool() if goal is not None else torch.zeros_like(x, dtype=torch.bool)
         if k == 0:
             return g.to(torch.uint8)
-        succ = g if k == 1 else ag.options[k - 1].in_initiation_set(x, y).bool()
+        parent = int(ag.ctx.parents[k])               # SPEC §4.2 skill graph (default chain: k - 1)
+        succ = g if parent == 0 else ag.options[parent].in_initiation_set(x, y).bool()
         fail = ~succ & ~self.in_initiation_set(x, y).bool()
         return (g | succ | fail).to(torch.uint8)

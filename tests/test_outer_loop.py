@@ -112,6 +112,27 @@ def test_discover_first_option_end_to_end():
 
 
 @pytest.mark.gpu
+def test_chain_skills_builds_a_chain():
+    """The whole outer loop (GPU only): options are created one after another, each chaining to the one before,
+    until the start state is covered or the option slots run out; created options get executed."""
+    import torch
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    agent = SkillChainingAgent("pinball_empty", 8192, 3, seed=5, epsilon=1.0, alpha=1e-4, max_episode_steps=400)
+    agent.enable_tracing(64)
+    agent.domain.reset_random(seed=11, v_max=0.5)
+    report = agent.chain_skills(steps_per_option=250, min_examples=2000, max_examples=20000, start_coverage=2.0)
+    assert len(report) >= 2, report
+    assert [r["option"] for r in report] == list(range(1, len(report) + 1))
+    assert all(r["parent"] == r["option"] - 1 and r["accuracy"] > 0.55 for r in report), report
+    for _ in range(5):
+        agent.step_batch()
+    ids = agent.state.option_id
+    assert int((ids == 1).sum()) > 0 and int((ids == 2).sum()) > 0
+    g = agent.skill_graph()
+    assert all(g.nodes[r["option"]]["enabled"] for r in report)
+
+
+@pytest.mark.gpu
 def test_batched_q_learning_learns_pinball():
     """The hot path is a learner, not just a throughput kernel: with the root value function only, goal
     arrivals per env-step must rise several-fold within 2500 step-batches (GPU only; no oracle involved)."""
