@@ -125,6 +125,13 @@ int scg_fit_initiation(scg_ctx *ctx, int32_t n_fit, const float *xy, const uint8
  * k -> k-1. Must be acyclic (every option reaches the goal). */
 int scg_set_option_parents(scg_ctx *ctx, const int32_t *parents);
 
+/* A learning scg_step also prepares the env order (SPEC §5) of the next step from the option ids it leaves.
+ * Call this after writing `option_id` by any other means (a reset, a restored checkpoint): the next scg_step
+ * then sorts afresh. Without it the step is still correct for the ids it finds, but groups and sums them in
+ * the stale order (slower, and not the canonical rounding). A different `option_id` pointer is noticed
+ * automatically. */
+int scg_invalidate_order(scg_ctx *ctx);
+
 /* ---- outer-loop support (SPEC §7): device-resident trajectory ring + per-step events,
  * so that the host skill-discovery loop never has to read env state every step.
  * scg_set_trace_buffers: caller-owned device buffers filled by every following scg_step (NULLs disable):

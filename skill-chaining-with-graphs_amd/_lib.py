@@ -62,6 +62,7 @@ _SIGS = {
     "scg_q_update": (C.c_int, [_P, C.c_int32, C.c_int32] + [_P] * 12 + [C.c_uint32, _P]),
     "scg_classifier_predict": (C.c_int, [_P, C.c_int32] + [_P] * 4 + [_P]),
     "scg_set_option_parents": (C.c_int, [_P, _P]),
+    "scg_invalidate_order": (C.c_int, [_P]),
     "scg_set_trace_buffers": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "scg_harvest": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "scg_profile_reset": (C.c_int, [_P, C.c_int32]),

@@ -106,10 +106,17 @@ class ScgContext:
         self._chk(W, f32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
         self._chk(clf, f32, self.n_vf * CLF_STRIDE, "clf")
         flags = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
+        if st is not getattr(self, "_last_state", None):      # another state object (its memory may be recycled)
+            self.invalidate_order()
+            self._last_state = st
         self._call("scg_step", _ptr(st.x), _ptr(st.y), _ptr(st.vx), _ptr(st.vy), _ptr(st.option_id),
                    _ptr(st.opt_steps), _ptr(st.ep_steps), _ptr(st.qcache), _ptr(st.action), _ptr(st.reward),
                    _ptr(st.done), _ptr(W), _ptr(clf), C.c_uint32(enabled_mask), C.c_uint64(t),
                    C.c_uint32(flags), self._stream())
+
+    def invalidate_order(self) -> None:
+        """Tell the library that option ids were written outside scg_step (reset, restore): re-sort next step."""
+        self._call("scg_invalidate_order")
 
     def set_option_parents(self, parents) -> None:
         """SPEC §4.2 option graph: parents[k] (k = 1..n_options) = option whose initiation set option k targets,

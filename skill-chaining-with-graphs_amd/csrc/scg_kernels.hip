@@ -695,15 +695,87 @@ struct ReduceArgs {
     int32_t nblk, n_vf;
     float alpha;
     uint32_t apply;
+    // next step's env order (SPEC §5), folded into the two reduce launches as extra workgroups (null = off)
+    const int32_t *option_id;
+    int32_t *hist, *perm;
+    int32_t n, nrow, nseg;
 };
 
 constexpr int RED_THREADS = 64;
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
 
+// SPEC §5 env order for the NEXT step, one wave per row of 256 envs (stable counting sort by option id, 7 keys:
+// out-of-range ids sort last). Runs as extra workgroups of the reduce launches, after the fused kernel has
+// written the new option ids; no LDS, no barriers.
+__device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, int n_vf) {
+    int o = e < n ? option_id[e] : -1;
+    if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;
+    return o;
+}
+
+__device__ __forceinline__ void row_hist(const int32_t *option_id, int n, int n_vf, int row, int32_t *hist) {
+    const int lane = threadIdx.x;
+    int o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = sort_key(option_id, row * 256 + j * 64 + lane, n, n_vf);
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c += __popcll(__ballot(o[j] == k));
+        if (lane == k) mine = c;
+    }
+    if (lane < 7) hist[row * 8 + lane] = mine;
+}
+
+__device__ __forceinline__ void row_scatter(const int32_t *option_id, int n, int n_vf, int nrow, int row,
+                                            const int32_t *hist, int32_t *perm) {
+    const int lane = threadIdx.x;
+    int tot[7], pre[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { tot[k] = 0; pre[k] = 0; }
+    for (int r = lane; r < nrow; r += 64) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int h = hist[r * 8 + k];
+            tot[k] += h;
+            if (r < row) pre[k] += h;
+        }
+    }
+    int off[7];
+    int before = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {                       // integer sums: any order
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
+        off[k] = before + pre[k];                       // (envs with a smaller key) + (key-k envs of earlier rows)
+        before += tot[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = row * 256 + j * 64 + lane;
+        const int o = sort_key(option_id, e, n, n_vf);
+        int pos = -1;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const uint64_t m = __ballot(o == k);
+            if (o == k) pos = off[k] + __popcll(m & ((1ull << lane) - 1ull));
+            off[k] += __popcll(m);
+        }
+        if (pos >= 0) perm[pos] = e;
+    }
+}
+
 // level 1: T_s = ((P_16s + P_16s+1) + ...) over the segment's non-empty blocks, all 16 loads in flight.
 // grid (column chunks, segments, n_vf): 26 x nblk/16 x n_vf workgroups stream the slabs once.
 __global__ __launch_bounds__(RED_THREADS) void reduce1_kernel(const ReduceArgs R) {
     const int k = blockIdx.z, sg = blockIdx.y, tid = threadIdx.x;
+    if (sg >= R.nseg) {                                  // extra workgroups: histogram rows of the next env order
+        const int row = ((sg - R.nseg) * R.n_vf + k) * (int)gridDim.x + blockIdx.x;
+        if (row < R.nrow) row_hist(R.option_id, R.n, R.n_vf, row, R.hist);
+        return;
+    }
     const int b0 = sg * SEG;
     const int i4 = blockIdx.x * RED_THREADS + tid;
     int tot = 0;
@@ -737,6 +809,11 @@ __global__ __launch_bounds__(RED_THREADS) void reduce1_kernel(const ReduceArgs R
 __global__ __launch_bounds__(RED_THREADS) void reduce2_kernel(const ReduceArgs R) {
     __shared__ int s_cnt[RED_THREADS];
     const int k = blockIdx.y, tid = threadIdx.x;
+    if (k >= R.n_vf) {                                   // extra workgroups: scatter rows of the next env order
+        const int row = (k - R.n_vf) * (int)gridDim.x + blockIdx.x;
+        if (row < R.nrow) row_scatter(R.option_id, R.n, R.n_vf, R.nrow, row, R.hist, R.perm);
+        return;
+    }
     const int nseg = (R.nblk + SEG - 1) / SEG;
     int c = 0;
     for (int sg = tid; sg < nseg; sg += RED_THREADS) c += R.segcnt[(size_t)sg * R.n_vf + k];
@@ -983,6 +1060,8 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step
+    bool order_valid;              // d_perm already holds the order of the ids in order_ids (made by the last learning step)
+    const int32_t *order_ids;
     uint32_t parents;              // packed option targets (default: the chain k -> k-1)
     float *ring_x, *ring_y;        // SPEC §7 caller-owned trace buffers (NULL = off)
     uint8_t *events;
@@ -1179,18 +1258,24 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.stamps = c->d_stamps;
 }
 
-static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStream_t s) {
+static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStream_t s,
+                         const int32_t *next_order_ids = nullptr) {
     ReduceArgs R;
     R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
     R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
     R.segs = c->d_segs; R.segcnt = c->d_segcnt;
     const int nseg = (nblk + SEG - 1) / SEG;
     const int ncol = (NACT * NF / 4 + RED_THREADS - 1) / RED_THREADS;
-    if (nseg > 0) {
-        hipLaunchKernelGGL(reduce1_kernel, dim3(ncol, nseg, c->n_vf), dim3(RED_THREADS), 0, s, R);
+    // the next step's env order rides along as extra workgroups of the same two launches
+    const int nrow = next_order_ids ? (c->cfg.n_envs + 255) / 256 : 0;
+    R.option_id = next_order_ids; R.hist = c->d_hist; R.perm = c->d_perm;
+    R.n = c->cfg.n_envs; R.nrow = nrow; R.nseg = nseg;
+    const int hy = (nrow + ncol * c->n_vf - 1) / (ncol * c->n_vf), sy = (nrow + ncol - 1) / ncol;
+    if (nseg + hy > 0) {
+        hipLaunchKernelGGL(reduce1_kernel, dim3(ncol, nseg + hy, c->n_vf), dim3(RED_THREADS), 0, s, R);
         SCG_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce2_kernel, dim3(ncol, c->n_vf), dim3(RED_THREADS), 0, s, R);
+    hipLaunchKernelGGL(reduce2_kernel, dim3(ncol, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
@@ -1215,11 +1300,16 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
     A.diag = (flags >> 12) & 0xfu;       // diagnostic only: early exits for phase timing
     // env order of this step (SPEC §5): counting sort by the option ids the previous step left
-    const int nrow = (c->cfg.n_envs + 255) / 256;        // the sort works on rows of 256 envs whatever the workgroup size
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->d_hist);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, nrow,
-                       c->d_hist, c->d_perm);
-    SCG_HIP(c, hipGetLastError());
+    // A learning step computes the NEXT step's order inside its reduce launches; the stand-alone sort runs only
+    // when that order is missing or was invalidated (first step, other array, scg_invalidate_order).
+    if (!(c->order_valid && c->order_ids == option_id)) {
+        const int nrow = (c->cfg.n_envs + 255) / 256;    // the sort works on rows of 256 envs whatever the workgroup size
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->d_hist);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, nrow,
+                           c->d_hist, c->d_perm);
+        SCG_HIP(c, hipGetLastError());
+    }
+    c->order_valid = false;
     A.perm = c->d_perm;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof_on) {
@@ -1236,7 +1326,17 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     hipLaunchKernelGGL(td_kernel<MODE_FUSED>, dim3(c->nblk), dim3(THREADS), LDS_BYTES, s, A);
     SCG_HIP(c, hipGetLastError());
     if (ev1) SCG_HIP(c, hipEventRecord(ev1, s));
-    if (flags & SCG_STEP_LEARN) return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s);
+    if (flags & SCG_STEP_LEARN) {
+        const int rc = launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s, option_id);
+        if (rc != SCG_OK) return rc;
+        c->order_valid = true; c->order_ids = option_id;
+    }
+    return SCG_OK;
+}
+
+int scg_invalidate_order(scg_ctx *c) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_invalidate_order: null ctx");
+    c->order_valid = false;
     return SCG_OK;
 }
 

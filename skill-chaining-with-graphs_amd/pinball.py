@@ -37,6 +37,7 @@ class PinballDomain:
             st.x.copy_(p[:, 0]); st.y.copy_(p[:, 1])
         st.vx.zero_(); st.vy.zero_()
         st.option_id.zero_(); st.opt_steps.zero_(); st.ep_steps.zero_(); st.qcache.zero_()
+        self.ctx.invalidate_order()               # option ids written outside scg_step
 
     def reset_random(self, seed: int = 0, v_max: float = 1.0) -> None:
         """Collision-free uniform positions and velocities in [-v_max, v_max] (steady-state timing)."""

@@ -161,6 +161,40 @@ def test_fused_step_act_only_and_split_apply():
     assert np.array_equal(W_d.cpu().numpy(), W_o)
 
 
+def test_env_order_prepared_by_the_previous_step_and_invalidated_on_outside_writes():
+    """A learning step leaves the next step's env order (SPEC §5) behind; acting-only steps and option ids
+    written by the caller (followed by scg_invalidate_order) fall back to a fresh sort. All bit-exact."""
+    import torch
+    n, n_options, mask = 3000, 3, 0b1110
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=n_options, seed=9, enabled_mask=mask)
+    clf = chain_classifiers(m, n_options)
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 3, vmax=1.0)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    W_o = random_weights(n_options + 1, 14, std=0.05)
+    st_d = state_to_device(st_o, ctx)
+    W_d, clf_d = dev(W_o.copy()), dev(clf)
+    G_d, n_d = ctx.grad_buffers()
+    rng = np.random.default_rng(5)
+    for t in range(14):
+        learn = t not in (4, 5, 9)                       # acting-only steps leave no prepared order
+        if t in (3, 7, 10):                              # the caller rewrites some option ids in place
+            idx = rng.choice(n, 500, replace=False)
+            st_o["option_id"][idx] = 0
+            st_o["opt_steps"][idx] = 0
+            st_d.option_id.copy_(torch.as_tensor(st_o["option_id"]))
+            st_d.opt_steps.copy_(torch.as_tensor(st_o["opt_steps"]))
+            ctx.invalidate_order()
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), mask, t, learn=learn)
+        assert_state_equal(st_d, st_o, msg=f"t={t}")
+        if learn:
+            orc.apply(W_o, G, n_k)
+            assert np.array_equal(G_d.cpu().numpy(), G), t
+        assert np.array_equal(W_d.cpu().numpy(), W_o), t
+    assert n_k[1:].sum() > 0
+
+
 def test_host_checks_fail_before_any_launch():
     from skill_chaining_with_graphs_amd import ScgError
     ctx, orc, m = make_pair("pinball_simple", 64)
