@@ -148,8 +148,9 @@ int scg_harvest(scg_ctx *ctx, int32_t n_sel, const int32_t *sel_env, const float
                 uint8_t *out_label, void *stream);
 
 /* ---- measurement hooks (bench.py's roofline leg) ----
- * scg_profile_reset(ctx, 1) makes every following scg_step record a HIP event pair round its fused
- * kernel on the launch stream; scg_profile_read synchronises those events and returns the summed
+ * scg_profile_reset(ctx, p) with p >= 1 makes every p-th following scg_step record a HIP event pair round
+ * its fused kernel on the launch stream (each pair costs a few microseconds of queue bubble, so sampling
+ * perturbs the timed region less); scg_profile_read synchronises those events and returns the summed
  * kernel time (ms) and the number of launches measured; scg_profile_reset(ctx, 0) stops recording. */
 int scg_profile_reset(scg_ctx *ctx, int32_t enable);
 int scg_profile_read(scg_ctx *ctx, double *kernel_ms_sum, int64_t *launches);

@@ -66,10 +66,25 @@ enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 #define SCG_STAMP(SEC) do { } while (0)
 #endif
 
+// global stores of per-step outputs: SCG_NT=1 marks them non-temporal (stream out of L2 during the kernel
+// instead of being written back at the end-of-kernel release)
+#ifndef SCG_NT
+#define SCG_NT 0
+#endif
+template <typename T>
+__device__ __forceinline__ void gstore(T *p, T v) {
+#if SCG_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct StepArgs {
     // env state (FUSED: in/out; TRANS/QVAL: in)
     float *x, *y, *vx, *vy;
     int32_t *option_id, *opt_steps, *ep_steps;
+    int32_t *hist_next;        // [rows of 256 envs][8] counts of the option ids this step leaves (null = off)
     float *qcache;                 // [5][n]  (QVAL: output q)
     uint8_t *action;               // FUSED: out; TRANS: in
     float *reward;                 // FUSED: out; TRANS: in (r)
@@ -226,16 +241,17 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
                 atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
-                A.action[e] = (uint8_t)a; A.reward[e] = rew; A.done[e] = (uint8_t)dn;
+                gstore(&A.action[e], (uint8_t)a); gstore(&A.reward[e], rew); gstore(&A.done[e], (uint8_t)dn);
                 if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
                     const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
                     A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
                 }
                 if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
-                A.x[e] = nx; A.y[e] = ny; A.vx[e] = nvx; A.vy[e] = nvy;
-                A.option_id[e] = on;
-                A.opt_steps[e] = keep ? osteps + 1 : 0;
-                A.ep_steps[e] = dn ? 0 : eps1;
+                gstore(&A.x[e], nx); gstore(&A.y[e], ny); gstore(&A.vx[e], nvx); gstore(&A.vy[e], nvy);
+                gstore(&A.option_id[e], (int32_t)on);
+                if (A.hist_next) atomicAdd(&A.hist_next[(e >> 8) * 8 + on], 1);   // next step's counting sort
+                gstore(&A.opt_steps[e], (int32_t)(keep ? osteps + 1 : 0));
+                gstore(&A.ep_steps[e], (int32_t)(dn ? 0 : eps1));
             } else if (MODE == MODE_TRANS) {
                 s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
                 s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         if (lane < GI && okl) {
                             if (s_on[il] == k) {
 #pragma unroll
-                                for (int a = 0; a < NACT; ++a) A.qcache[(size_t)a * N + s_env[il]] = qo[a];
+                                for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
                             }
                             float mx = qo[0];
 #pragma unroll
@@ -663,7 +679,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         const int idx = 64 * (j - 18) + l;
                         if (idx < 144) f = (idx >> 2) * 36 + 32 + (idx & 3);
                     }
-                    if (f >= 0) slab[a * NF + f] = sum;
+                    if (f >= 0) gstore(&slab[a * NF + f], sum);
                 }
             }
         }
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// slabs -> G (block order), n_k; optional apply (SPEC §5)
+// slabs -> G (SPEC §5 two-level block order), n_k, optional apply; the next step's env order rides along
 struct ReduceArgs {
     const float *slabs;
     const int32_t *cnts;
@@ -690,48 +706,33 @@ struct ReduceArgs {
     int32_t *n_k;
     float *W;
     const float *scale;
-    float *segs;             // [nseg][n_vf][5][1296] first-level partial sums
-    int32_t *segcnt;         // [nseg][n_vf]
     int32_t nblk, n_vf;
     float alpha;
     uint32_t apply;
-    // next step's env order (SPEC §5), folded into the two reduce launches as extra workgroups (null = off)
+    // next step's env order (SPEC §5) as extra workgroups (option_id null = off): the fused kernel has counted
+    // the new option ids per row of 256 envs into `hist`; `hist_zero` is the other buffer, cleared for the next step
     const int32_t *option_id;
-    int32_t *hist, *perm;
-    int32_t n, nrow, nseg;
+    int32_t *hist, *hist_zero, *perm;
+    int32_t n, nrow;
 };
 
-constexpr int RED_THREADS = 64;
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
+constexpr int RED_WAVES = 16;      // one wave per segment, 16 segments per round
+constexpr int RED_THREADS = 64 * RED_WAVES;
+constexpr int RED_COLS = NACT * NF / 4;                              // float4 columns per value function
+constexpr int RED_NCOL = (RED_COLS + 63) / 64;
 
-// SPEC §5 env order for the NEXT step, one wave per row of 256 envs (stable counting sort by option id, 7 keys:
-// out-of-range ids sort last). Runs as extra workgroups of the reduce launches, after the fused kernel has
-// written the new option ids; no LDS, no barriers.
 __device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, int n_vf) {
     int o = e < n ? option_id[e] : -1;
     if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;
     return o;
 }
 
-__device__ __forceinline__ void row_hist(const int32_t *option_id, int n, int n_vf, int row, int32_t *hist) {
-    const int lane = threadIdx.x;
-    int o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = sort_key(option_id, row * 256 + j * 64 + lane, n, n_vf);
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c += __popcll(__ballot(o[j] == k));
-        if (lane == k) mine = c;
-    }
-    if (lane < 7) hist[row * 8 + lane] = mine;
-}
-
+// One wave places a row of 256 envs in the stable counting-sort order (7 keys; out-of-range ids sort last),
+// given the per-row key counts of all rows. No LDS, no barriers.
 __device__ __forceinline__ void row_scatter(const int32_t *option_id, int n, int n_vf, int nrow, int row,
                                             const int32_t *hist, int32_t *perm) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     int tot[7], pre[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) { tot[k] = 0; pre[k] = 0; }
@@ -767,89 +768,74 @@ __device__ __forceinline__ void row_scatter(const int32_t *option_id, int n, int
     }
 }
 
-// level 1: T_s = ((P_16s + P_16s+1) + ...) over the segment's non-empty blocks, all 16 loads in flight.
-// grid (column chunks, segments, n_vf): 26 x nblk/16 x n_vf workgroups stream the slabs once.
-__global__ __launch_bounds__(RED_THREADS) void reduce1_kernel(const ReduceArgs R) {
-    const int k = blockIdx.z, sg = blockIdx.y, tid = threadIdx.x;
-    if (sg >= R.nseg) {                                  // extra workgroups: histogram rows of the next env order
-        const int row = ((sg - R.nseg) * R.n_vf + k) * (int)gridDim.x + blockIdx.x;
-        if (row < R.nrow) row_hist(R.option_id, R.n, R.n_vf, row, R.hist);
+// grid (column chunks, n_vf [+ rows of the env order]). A workgroup owns 64 float4 columns of one value function;
+// its 16 waves each sum one segment's slabs, T_s = ((P_16s + P_16s+1) + ...) over the non-empty blocks with all
+// 16 loads in flight, park T_s in LDS, and wave 0 adds the non-empty segments in order, G = ((T_0 + T_1) + ...)
+// — SPEC §5's two levels in one launch.
+__global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
+    __shared__ float4 s_T[RED_WAVES][64];
+    __shared__ int s_cnt[RED_WAVES];
+    const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (k >= R.n_vf) {                                   // extra workgroups: one row of the next env order per wave
+        const int row = ((k - R.n_vf) * (int)gridDim.x + blockIdx.x) * RED_WAVES + wave;
+        if (row < R.nrow) {
+            row_scatter(R.option_id, R.n, R.n_vf, R.nrow, row, R.hist, R.perm);
+            if (lane < 8) R.hist_zero[row * 8 + lane] = 0;
+        }
         return;
     }
-    const int b0 = sg * SEG;
-    const int i4 = blockIdx.x * RED_THREADS + tid;
-    int tot = 0;
-    bool on[SEG];
-#pragma unroll
-    for (int u = 0; u < SEG; ++u) {
-        const int b = b0 + u;
-        const int c = b < R.nblk ? R.cnts[(size_t)b * R.n_vf + k] : 0;     // wave-uniform
-        on[u] = c > 0;
-        tot += c;
-    }
-    if (blockIdx.x == 0 && tid == 0) R.segcnt[(size_t)sg * R.n_vf + k] = tot;
-    if (i4 >= NACT * NF / 4 || tot == 0) return;
-    const size_t stride4 = (size_t)R.n_vf * NACT * NF / 4;
-    const float4 *p = reinterpret_cast<const float4 *>(R.slabs) + (size_t)k * (NACT * NF / 4) + i4;
-    float4 v[SEG];
-#pragma unroll
-    for (int u = 0; u < SEG; ++u) {
-        v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (on[u]) v[u] = p[(size_t)(b0 + u) * stride4];
-    }
-    float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-    for (int u = 0; u < SEG; ++u) {
-        if (on[u]) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
-    }
-    reinterpret_cast<float4 *>(R.segs)[((size_t)sg * R.n_vf + k) * (NACT * NF / 4) + i4] = T;
-}
-
-// level 2: G = ((T_0 + T_1) + ...) over non-empty segments, n_k, optional apply (SPEC §5)
-__global__ __launch_bounds__(RED_THREADS) void reduce2_kernel(const ReduceArgs R) {
-    __shared__ int s_cnt[RED_THREADS];
-    const int k = blockIdx.y, tid = threadIdx.x;
-    if (k >= R.n_vf) {                                   // extra workgroups: scatter rows of the next env order
-        const int row = (k - R.n_vf) * (int)gridDim.x + blockIdx.x;
-        if (row < R.nrow) row_scatter(R.option_id, R.n, R.n_vf, R.nrow, row, R.hist, R.perm);
-        return;
-    }
+    const int i4 = blockIdx.x * 64 + lane;
+    const bool live = i4 < RED_COLS;
+    const size_t stride4 = (size_t)R.n_vf * RED_COLS;
+    const float4 *p = reinterpret_cast<const float4 *>(R.slabs) + (size_t)k * RED_COLS + (live ? i4 : 0);
     const int nseg = (R.nblk + SEG - 1) / SEG;
-    int c = 0;
-    for (int sg = tid; sg < nseg; sg += RED_THREADS) c += R.segcnt[(size_t)sg * R.n_vf + k];
-    s_cnt[tid] = c;
-    __syncthreads();
-    for (int s = RED_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) s_cnt[tid] += s_cnt[tid + s];
+    float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int nk = 0;
+    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES) {
+        const int b0 = (sg0 + wave) * SEG;
+        const int bl = b0 + lane;
+        int c = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
+        const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
+#pragma unroll
+        for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
+        float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (mask) {
+            float4 v[SEG];
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) {
+                v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if ((mask >> u) & 1u) v[u] = p[(size_t)(b0 + u) * stride4];
+            }
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) {
+                if ((mask >> u) & 1u) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
+            }
+        }
+        s_T[wave][lane] = T;
+        if (lane == 0) s_cnt[wave] = c;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int u = 0; u < RED_WAVES; ++u) {
+                const int cu = s_cnt[u];
+                if (cu > 0) {
+                    const float4 t = s_T[u][lane];
+                    S.x = S.x + t.x; S.y = S.y + t.y; S.z = S.z + t.z; S.w = S.w + t.w;
+                    nk += cu;
+                }
+            }
+        }
         __syncthreads();
     }
-    const int nk = s_cnt[0];
-    if (blockIdx.x == 0 && tid == 0) R.n_k[k] = nk;
-    const int i4 = blockIdx.x * RED_THREADS + tid;
-    if (i4 >= NACT * NF / 4) return;
-    float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4 *p = reinterpret_cast<const float4 *>(R.segs) + (size_t)k * (NACT * NF / 4) + i4;
-    const size_t stride4 = (size_t)R.n_vf * NACT * NF / 4;
-    for (int s0 = 0; s0 < nseg; s0 += SEG) {               // 16 segment sums in flight, added in segment order
-        float4 t[SEG];
-        bool on[SEG];
-#pragma unroll
-        for (int u = 0; u < SEG; ++u) {
-            on[u] = s0 + u < nseg && R.segcnt[(size_t)(s0 + u) * R.n_vf + k] > 0;     // wave-uniform
-            t[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (on[u]) t[u] = p[(size_t)(s0 + u) * stride4];
-        }
-#pragma unroll
-        for (int u = 0; u < SEG; ++u) {
-            if (on[u]) { S.x = S.x + t[u].x; S.y = S.y + t[u].y; S.z = S.z + t[u].z; S.w = S.w + t[u].w; }
-        }
-    }
-    reinterpret_cast<float4 *>(R.G)[(size_t)k * (NACT * NF / 4) + i4] = S;
+    if (wave != 0) return;
+    if (blockIdx.x == 0 && lane == 0) R.n_k[k] = nk;
+    if (!live) return;
+    reinterpret_cast<float4 *>(R.G)[(size_t)k * RED_COLS + i4] = S;
     if (R.apply && nk > 0) {
         const float step = R.alpha / (float)nk;
         const int f = (i4 * 4) % NF;                                       // NF % 4 == 0: no row straddling
         const float4 sc = *reinterpret_cast<const float4 *>(R.scale + f);
-        float4 *wp = reinterpret_cast<float4 *>(R.W) + (size_t)k * (NACT * NF / 4) + i4;
+        float4 *wp = reinterpret_cast<float4 *>(R.W) + (size_t)k * RED_COLS + i4;
         float4 w = *wp;
         w.x = fmaf(step * sc.x, S.x, w.x); w.y = fmaf(step * sc.y, S.y, w.y);
         w.z = fmaf(step * sc.z, S.z, w.z); w.w = fmaf(step * sc.w, S.w, w.w);
@@ -1059,7 +1045,10 @@ struct scg_ctx {
     MapScalars ms;
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
-    int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step
+    int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
+    int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
+    int hist_parity;
+    bool hist_dirty;               // a failed call may have left counts behind: clear both before the next use
     bool order_valid;              // d_perm already holds the order of the ids in order_ids (made by the last learning step)
     const int32_t *order_ids;
     uint32_t parents;              // packed option targets (default: the chain k -> k-1)
@@ -1072,11 +1061,11 @@ struct scg_ctx {
     int32_t *d_cnts;
     float *d_G;
     int32_t *d_nk;
-    float *d_segs;
-    int32_t *d_segcnt;
     float *G_out;          // where reduce leaves G / n_k (ctx-owned by default)
     int32_t *nk_out;
     bool prof_on;          // measurement hook: event pairs round the fused kernel
+    int prof_every;        // ... of every prof_every-th launch (events cost a few us of queue bubble each)
+    long long prof_seen;
     std::vector<hipEvent_t> *prof_ev;
     size_t prof_used;
     char err[256];
@@ -1143,14 +1132,16 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_slabs, slab_bytes) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_cnts, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_G, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        const size_t nseg = (size_t)(c->nblk + SEG - 1) / SEG;
-        if (hipMalloc(&c->d_segs, nseg * c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipMalloc(&c->d_segcnt, nseg * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_nk, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_edges, MAX_EDGES * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        {
+            const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * 8 * sizeof(int32_t);
+            if (hipMalloc(&c->d_hist2[0], hb) != hipSuccess || hipMalloc(&c->d_hist2[1], hb) != hipSuccess) { st = SCG_ERR_HIP; break; }
+            if (hipMemset(c->d_hist2[0], 0, hb) != hipSuccess || hipMemset(c->d_hist2[1], 0, hb) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        }
         if (hipMalloc(&c->d_cellmask, (size_t)CELL_G * CELL_G * 4 * sizeof(uint64_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_G, 0, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
@@ -1181,7 +1172,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
 int scg_destroy(scg_ctx *c) {
     if (!c) return SCG_OK;
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
-    (void)hipFree(c->d_segs); (void)hipFree(c->d_segcnt);
+    (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
@@ -1263,19 +1254,13 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
     ReduceArgs R;
     R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
     R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
-    R.segs = c->d_segs; R.segcnt = c->d_segcnt;
-    const int nseg = (nblk + SEG - 1) / SEG;
-    const int ncol = (NACT * NF / 4 + RED_THREADS - 1) / RED_THREADS;
-    // the next step's env order rides along as extra workgroups of the same two launches
+    // the next step's env order rides along as extra workgroups of the same launch
     const int nrow = next_order_ids ? (c->cfg.n_envs + 255) / 256 : 0;
-    R.option_id = next_order_ids; R.hist = c->d_hist; R.perm = c->d_perm;
-    R.n = c->cfg.n_envs; R.nrow = nrow; R.nseg = nseg;
-    const int hy = (nrow + ncol * c->n_vf - 1) / (ncol * c->n_vf), sy = (nrow + ncol - 1) / ncol;
-    if (nseg + hy > 0) {
-        hipLaunchKernelGGL(reduce1_kernel, dim3(ncol, nseg + hy, c->n_vf), dim3(RED_THREADS), 0, s, R);
-        SCG_HIP(c, hipGetLastError());
-    }
-    hipLaunchKernelGGL(reduce2_kernel, dim3(ncol, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
+    R.option_id = next_order_ids; R.perm = c->d_perm;
+    R.hist = c->d_hist2[c->hist_parity]; R.hist_zero = c->d_hist2[c->hist_parity ^ 1];
+    R.n = c->cfg.n_envs; R.nrow = nrow;
+    const int sy = (nrow + RED_NCOL * RED_WAVES - 1) / (RED_NCOL * RED_WAVES);
+    hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
@@ -1310,9 +1295,17 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
         SCG_HIP(c, hipGetLastError());
     }
     c->order_valid = false;
+    if (c->hist_dirty) {
+        const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * 8 * sizeof(int32_t);
+        SCG_HIP(c, hipMemsetAsync(c->d_hist2[0], 0, hb, s));
+        SCG_HIP(c, hipMemsetAsync(c->d_hist2[1], 0, hb, s));
+        c->hist_dirty = false;
+    }
+    const bool fold = (flags & SCG_STEP_LEARN) && !(flags & 0x200u);      // 0x200: diagnostic, sort afresh every step
+    A.hist_next = fold ? c->d_hist2[c->hist_parity] : nullptr;
     A.perm = c->d_perm;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (c->prof_on) {
+    if (c->prof_on && (c->prof_seen++ % c->prof_every) == 0) {
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
         while (c->prof_ev->size() < c->prof_used + 2) {
             hipEvent_t e;
@@ -1327,8 +1320,12 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     SCG_HIP(c, hipGetLastError());
     if (ev1) SCG_HIP(c, hipEventRecord(ev1, s));
     if (flags & SCG_STEP_LEARN) {
+        if (!fold) return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s);
+        c->hist_dirty = true;                      // until the reduce launch has consumed and re-armed the counts
         const int rc = launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s, option_id);
         if (rc != SCG_OK) return rc;
+        c->hist_dirty = false;
+        c->hist_parity ^= 1;
         c->order_valid = true; c->order_ids = option_id;
     }
     return SCG_OK;
@@ -1394,7 +1391,9 @@ int scg_harvest(scg_ctx *c, int32_t n_sel, const int32_t *sel_env, const float *
 
 int scg_profile_reset(scg_ctx *c, int32_t enable) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_profile_reset: null ctx");
-    c->prof_on = enable != 0;
+    c->prof_on = enable > 0;
+    c->prof_every = enable > 0 ? enable : 1;
+    c->prof_seen = 0;
     c->prof_used = 0;
     return SCG_OK;
 }
