@@ -120,6 +120,21 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for LDS hand-offs only. __syncthreads() carries a workgroup-scope release fence, which on
+// gfx9 means s_waitcnt vmcnt(0): every barrier after a global store waits for the store to be acknowledged
+// (≈ 9 us after phase P's scattered state stores, and again after every slab chunk). Nothing in td_kernel
+// passes data between threads through global memory, so the barriers only need this wave's LDS traffic done.
+#ifndef SCG_LDS_BARRIER
+#define SCG_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void block_lds_sync() {
+#if SCG_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 __device__ __forceinline__ bool in_set(const StepArgs &A, int k, float x, float y) {
     if (k < 1 || k >= A.n_vf) return false;
     if (!((A.enabled >> k) & 1u)) return false;
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
         if (tid == 0) s_misc[31] = 1;                      // bit k: some env of this workgroup has an item for VF k
         if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
-        __syncthreads();
+        block_lds_sync();
     }
 
     if (MODE == MODE_FUSED && A.diag == 1) return;
@@ -241,6 +256,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
                 atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
+                if (A.diag == 5) { A.reward[e] = rew + ro + co + (float)on; return; }
                 gstore(&A.action[e], (uint8_t)a); gstore(&A.reward[e], rew); gstore(&A.done[e], (uint8_t)dn);
                 if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
                     const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255;
         }
     }
-    __syncthreads();
+    block_lds_sync();
 
     if (MODE == MODE_FUSED && A.diag >= 2) return;
     SCG_STAMP(0);   // phase P
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = 0;
             continue;
         }
-        __syncthreads();
+        block_lds_sync();
         // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 256 envs:
         //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), env order
         //   update lists: envs that update VF k, one run per action a_t, env order inside a run
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_misc[wave * 8 + lane] = __popcll(mine);
             }
         }
-        __syncthreads();
+        block_lds_sync();
         int n_ev = 0, run_len[NACT], run_off[NACT], qbase[NACT + 1];
         {
             int se = 0;
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_ulist[ro + off + __popcll(mine & below)] = (uint16_t)tid;
             }
         }
-        __syncthreads();
+        block_lds_sync();
         if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = nupd;
         SCG_STAMP(k == 0 ? 1 : 8);    // phase Z (first pass only) + list build
         if (n_ev + nupd == 0) continue;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             const float4 *Wk4 = reinterpret_cast<const float4 *>(A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF));
             float4 *b4 = reinterpret_cast<float4 *>(s_buf);
             for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) b4[f4] = Wk4[f4];
-            __syncthreads();
+            block_lds_sync();
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
 #pragma unroll
@@ -495,7 +511,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     SCG_R_SET(a, 18 + t, (t < 2 || v20) ? v : 0.0f);
                 }
             }
-            __syncthreads();                                       // the staging area becomes table scratch
+            block_lds_sync();                                       // the staging area becomes table scratch
         } else {
             // 128-env workgroups (two per CU): no LDS room for the 26 KB staging area — every wave fetches its
             // 105 weights per lane through the buffer descriptor (L2-resident)
@@ -569,7 +585,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
         if (MODE == MODE_QVAL || nupd == 0) continue;
         SCG_STAMP(k == 0 ? 3 : 10);   // loop A (wave 0's share)
-        __syncthreads();                                   // s_maxq crosses waves (loop B deals quads differently)
+        block_lds_sync();                                   // s_maxq crosses waves (loop B deals quads differently)
 
         SCG_STAMP(k == 0 ? 4 : 11);   // wait for the other waves' loop A
         // ---- loop BC (accumulator live, one row of W_k at a time): for each action run, for this wave's quads:
@@ -659,13 +675,13 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             float *park = s_scr + wave * SCR_WAVE_FLOATS + lane;       // [wave][15][64]
 #pragma unroll
             for (int c = 0; c < NSLOT / 3; ++c) {
-                __syncthreads();                                       // scratch free (tables / previous chunk)
+                block_lds_sync();                                       // scratch free (tables / previous chunk)
 #pragma unroll
                 for (int a = 0; a < NACT; ++a) {
 #pragma unroll
                     for (int jj = 0; jj < 3; ++jj) park[(a * 3 + jj) * 64] = Acc[a][3 * c + jj];
                 }
-                __syncthreads();
+                block_lds_sync();
                 for (int o = tid; o < 15 * 64; o += THREADS) {
                     const int l = o & 63, v15 = o >> 6;
                     const int a = v15 / 3, j = 3 * c + (v15 - 3 * a);

@@ -31,3 +31,7 @@ mean = out.astype(np.float64).mean(0) / args.steps
 tot = mean.sum()
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
 for nme, v in zip(names, mean): print(f"  {nme:22s} {v:10.0f}  {100*v/tot:5.1f} %")
+per_block = out.astype(np.float64).sum(1) / args.steps
+print(f"per-block wave-0 total ticks per launch: min {per_block.min():.0f}  mean {per_block.mean():.0f}  max {per_block.max():.0f}"
+      f"  (mean/max = {per_block.mean()/per_block.max():.2f}: one workgroup per CU, the launch lasts as long as its slowest)")
+print("  by block index (sorted env order, 16 blocks per bin):", np.round(per_block.reshape(-1, 16).mean(1)).astype(int).tolist())
