@@ -118,7 +118,6 @@ def main():
     ap.add_argument("--no-learn", action="store_true", help="diagnostic: act + physics + qcache only")
     ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
     ap.add_argument("--diag-fresh-sort", action="store_true", help="diagnostic: stand-alone sort kernels every step")
-    ap.add_argument("--diag-exit", type=int, default=0, help="diagnostic: 1 = exit before phase P, 2 = after phase P")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--event-every", type=int, default=8, help="HIP event pair round every n-th fused-kernel launch")
     args = ap.parse_args()
@@ -167,7 +166,7 @@ def main():
         torch.cuda.synchronize()
 
     learn = not args.no_learn
-    if args.diag_no_td or args.diag_exit or args.diag_fresh_sort:
+    if args.diag_no_td or args.diag_fresh_sort:
         import ctypes as _C
         from skill_chaining_with_graphs_amd.core import _ptr
         def _step(_learn=True):
@@ -175,7 +174,7 @@ def main():
             agent.ctx._call("scg_step", _ptr(st.x), _ptr(st.y), _ptr(st.vx), _ptr(st.vy), _ptr(st.option_id),
                             _ptr(st.opt_steps), _ptr(st.ep_steps), _ptr(st.qcache), _ptr(st.action),
                             _ptr(st.reward), _ptr(st.done), _ptr(agent.W), _ptr(agent.clf),
-                            _C.c_uint32(agent.enabled_mask), _C.c_uint64(agent.t), _C.c_uint32((0x203 if args.diag_fresh_sort else 0x100) | (args.diag_exit << 12)),
+                            _C.c_uint32(agent.enabled_mask), _C.c_uint64(agent.t), _C.c_uint32(0x203 if args.diag_fresh_sort else 0x100),
                             agent.ctx._stream())
             agent.t += 1
         agent.step_batch = _step

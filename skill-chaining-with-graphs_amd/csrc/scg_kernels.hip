@@ -85,6 +85,8 @@ struct StepArgs {
     float *x, *y, *vx, *vy;
     int32_t *option_id, *opt_steps, *ep_steps;
     int32_t *hist_next;        // [rows of 256 envs][8] counts of the option ids this step leaves (null = off)
+    float4 *outrec;            // FUSED: [positions][2] per-env results in env-ORDER position, committed to the
+                               // caller's arrays by commit_row (coalesced) instead of 4-byte scatters from here
     float *qcache;                 // [5][n]  (QVAL: output q)
     uint8_t *action;               // FUSED: out; TRANS: in
     float *reward;                 // FUSED: out; TRANS: in (r)
@@ -105,7 +107,7 @@ struct StepArgs {
     int32_t *cnts;                 // [nblk][n_vf]
     unsigned long long *stamps;    // diagnostic build only
     int32_t n, n_vf, k_lo, k_hi;
-    uint32_t enabled, learn, diag;
+    uint32_t enabled, learn;
     uint32_t parents;              // 3 bits per option k at [3k, 3k+3): target option of k (0 = the task goal)
     uint64_t t, seed;
     int64_t env_base;
@@ -178,7 +180,6 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         block_lds_sync();
     }
 
-    if (MODE == MODE_FUSED && A.diag == 1) return;
     // ------------------------------------------------------------------ phase P
     if (lane < 32) {                                  // 8 waves x 32 lanes: two waves per SIMD hide LDS latency
         const int i = wave * 32 + lane;
@@ -205,11 +206,9 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 const int ep0 = A.ep_steps[e], o = A.option_id[e], osteps = A.opt_steps[e];   // early: latency hides under the physics
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
-                if (A.diag == 3) { A.action[e] = (uint8_t)a; return; }
                 // physics (SPEC §1.3)
                 bool goal;
                 const float rew = pinball_step_any(s_edges, A.cellmask, A.ms, sx, sy, svx, svy, a, goal);
-                if (A.diag == 4) { A.reward[e] = rew + sx + sy + svx + svy; return; }
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = ep0 + 1;
                 const bool timeout = !goal && eps1 >= A.max_ep;
@@ -256,18 +255,22 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
                 atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
-                if (A.diag == 5) { A.reward[e] = rew + ro + co + (float)on; return; }
-                gstore(&A.action[e], (uint8_t)a); gstore(&A.reward[e], rew); gstore(&A.done[e], (uint8_t)dn);
+                // results -> staging record at this env's POSITION (full-line stores); commit_row scatters them
+                // to the caller's arrays in env order. (Direct 4-byte stores from here dirtied every 64-byte line
+                // from ~6 workgroups on different XCDs: ≈ 9 us of partial-line writes per step.)
+                {
+                    const int osn = keep ? osteps + 1 : 0, epn = dn ? 0 : eps1;
+                    float4 *orec = A.outrec + (size_t)(e0 + i) * 2;
+                    orec[0] = make_float4(nx, ny, nvx, nvy);
+                    orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
+                                          __int_as_float(osn), __int_as_float(epn));
+                }
                 if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
                     const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
                     A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
                 }
                 if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
-                gstore(&A.x[e], nx); gstore(&A.y[e], ny); gstore(&A.vx[e], nvx); gstore(&A.vy[e], nvy);
-                gstore(&A.option_id[e], (int32_t)on);
                 if (A.hist_next) atomicAdd(&A.hist_next[(e >> 8) * 8 + on], 1);   // next step's counting sort
-                gstore(&A.opt_steps[e], (int32_t)(keep ? osteps + 1 : 0));
-                gstore(&A.ep_steps[e], (int32_t)(dn ? 0 : eps1));
             } else if (MODE == MODE_TRANS) {
                 s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
                 s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
@@ -288,7 +291,6 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     }
     block_lds_sync();
 
-    if (MODE == MODE_FUSED && A.diag >= 2) return;
     SCG_STAMP(0);   // phase P
     // ------------------------------------------------------------------ phase Z (SPEC §3)
     {
@@ -730,6 +732,14 @@ struct ReduceArgs {
     const int32_t *option_id;
     int32_t *hist, *hist_zero, *perm;
     int32_t n, nrow;
+    // commit of the fused kernel's per-position results to the caller's arrays (outrec null = off), one row of
+    // 256 envs per wave; with `sort` the same wave then places its row in the next env order
+    const float4 *outrec;
+    int32_t *invperm;              // [n] position of env e in the current order (in: this step's, out: the next's)
+    float *x, *y, *vx, *vy, *reward;
+    int32_t *option_id_out, *opt_steps, *ep_steps;
+    uint8_t *action, *done;
+    int32_t sort;
 };
 
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
@@ -744,44 +754,74 @@ __device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, 
     return o;
 }
 
-// One wave places a row of 256 envs in the stable counting-sort order (7 keys; out-of-range ids sort last),
-// given the per-row key counts of all rows. No LDS, no barriers.
-__device__ __forceinline__ void row_scatter(const int32_t *option_id, int n, int n_vf, int nrow, int row,
-                                            const int32_t *hist, int32_t *perm) {
+// One wave per row of 256 envs (no LDS, no barriers), two dependent memory round trips in all:
+//   commit: gather each env's result record from its position in the current order (one 32-byte read) and write
+//           the caller's SoA arrays with full-line stores;
+//   sort  : place the row in the stable counting-sort order of the next step (7 keys), from the per-row key
+//           counts of all rows: offset(key k, row) = (envs with a smaller key) + (key-k envs of earlier rows).
+// Load order matters: positions first, then the count table, then the records, so that the table's latency hides
+// under the records' and the prefix sums run while the records are in flight.
+__device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int row) {
     const int lane = threadIdx.x & 63;
+    int pos_old[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = row * 256 + j * 64 + lane;
+        pos_old[j] = e < R.n ? R.invperm[e] : 0;
+    }
     int tot[7], pre[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) { tot[k] = 0; pre[k] = 0; }
-    for (int r = lane; r < nrow; r += 64) {
+    if (R.sort) {
+        for (int r = lane; r < R.nrow; r += 64) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int h = hist[r * 8 + k];
-            tot[k] += h;
-            if (r < row) pre[k] += h;
+            for (int k = 0; k < 7; ++k) {
+                const int h = R.hist[r * 8 + k];
+                tot[k] += h;
+                if (r < row) pre[k] += h;
+            }
         }
     }
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 *r = R.outrec + (size_t)pos_old[j] * 2;
+        ra[j] = r[0]; rb[j] = r[1];
+    }
     int off[7];
-    int before = 0;
+    if (R.sort) {
+        int before = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {                       // integer sums: any order
+        for (int k = 0; k < 7; ++k) {                   // integer sums: any order
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
-        off[k] = before + pre[k];                       // (envs with a smaller key) + (key-k envs of earlier rows)
-        before += tot[k];
+            for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
+            off[k] = before + pre[k];
+            before += tot[k];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = row * 256 + j * 64 + lane;
-        const int o = sort_key(option_id, e, n, n_vf);
-        int pos = -1;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const uint64_t m = __ballot(o == k);
-            if (o == k) pos = off[k] + __popcll(m & ((1ull << lane) - 1ull));
-            off[k] += __popcll(m);
+        int key = -1;
+        if (e < R.n) {
+            const unsigned bits = __float_as_uint(rb[j].y);
+            key = (int)((bits >> 16) & 255u);
+            R.x[e] = ra[j].x; R.y[e] = ra[j].y; R.vx[e] = ra[j].z; R.vy[e] = ra[j].w;
+            R.reward[e] = rb[j].x; R.action[e] = (uint8_t)(bits & 255u); R.done[e] = (uint8_t)((bits >> 8) & 255u);
+            R.option_id_out[e] = key; R.opt_steps[e] = __float_as_int(rb[j].z); R.ep_steps[e] = __float_as_int(rb[j].w);
         }
-        if (pos >= 0) perm[pos] = e;
+        if (R.sort) {
+            int pos = -1;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const uint64_t m = __ballot(key == k);
+                if (key == k) pos = off[k] + __popcll(m & ((1ull << lane) - 1ull));
+                off[k] += __popcll(m);
+            }
+            if (pos >= 0) { R.perm[pos] = e; R.invperm[e] = pos; }
+        }
     }
+    if (R.sort && lane < 8) R.hist_zero[row * 8 + lane] = 0;
 }
 
 // grid (column chunks, n_vf [+ rows of the env order]). A workgroup owns 64 float4 columns of one value function;
@@ -791,13 +831,12 @@ __device__ __forceinline__ void row_scatter(const int32_t *option_id, int n, int
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
     __shared__ float4 s_T[RED_WAVES][64];
     __shared__ int s_cnt[RED_WAVES];
-    const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (k >= R.n_vf) {                                   // extra workgroups: one row of the next env order per wave
-        const int row = ((k - R.n_vf) * (int)gridDim.x + blockIdx.x) * RED_WAVES + wave;
-        if (row < R.nrow) {
-            row_scatter(R.option_id, R.n, R.n_vf, R.nrow, row, R.hist, R.perm);
-            if (lane < 8) R.hist_zero[row * 8 + lane] = 0;
-        }
+    const int sy = (int)gridDim.y - R.n_vf;              // leading workgroups: one env row per wave (dispatched first:
+    const int k = (int)blockIdx.y - sy;                  // their chain of dependent accesses is the launch's long pole)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (k < 0) {
+        const int row = (int)blockIdx.y * (int)gridDim.x + blockIdx.x;      // one row per workgroup (wave 0): a row
+        if (wave == 0 && row < R.nrow) commit_and_place_row(R, row);        // moves ~25 KB, so spread them over the CUs
         return;
     }
     const int i4 = blockIdx.x * 64 + lane;
@@ -859,6 +898,12 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     }
 }
 
+// acting-only steps have no reduce launch: the commit alone, one wave per row of 256 envs
+__global__ __launch_bounds__(256) void commit_kernel(const ReduceArgs R) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < R.nrow) commit_and_place_row(R, row);
+}
+
 __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, const int32_t *n_k,
                                                     const float *scale, float alpha) {
     const int k = blockIdx.y;
@@ -891,7 +936,7 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const int32_t *option_id
 }
 
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option_id, int n, int n_vf, int nblk,
-                                                           const int32_t *hist, int32_t *perm) {
+                                                           const int32_t *hist, int32_t *perm, int32_t *invperm) {
     __shared__ int s_c[4][8];
     __shared__ int s_off[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -943,6 +988,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
         int pos = s_off[o] + rank;
         for (int w = 0; w < wave; ++w) pos += s_c[w][o];
         perm[pos] = e;
+        invperm[e] = pos;
     }
 }
 
@@ -1062,6 +1108,8 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
+    float4 *d_outrec;              // [nblk * BLOCK_ENVS][2] per-position step results (td_kernel -> commit_row)
+    int32_t *d_invperm;            // [n_envs] position of each env in d_perm
     int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
     int hist_parity;
     bool hist_dirty;               // a failed call may have left counts behind: clear both before the next use
@@ -1153,6 +1201,8 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_outrec, (size_t)c->nblk * BLOCK_ENVS * 2 * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_invperm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         {
             const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * 8 * sizeof(int32_t);
             if (hipMalloc(&c->d_hist2[0], hb) != hipSuccess || hipMalloc(&c->d_hist2[1], hb) != hipSuccess) { st = SCG_ERR_HIP; break; }
@@ -1188,7 +1238,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
 int scg_destroy(scg_ctx *c) {
     if (!c) return SCG_OK;
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
-    (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]);
+    (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]); (void)hipFree(c->d_outrec); (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
@@ -1265,17 +1315,29 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.stamps = c->d_stamps;
 }
 
+// The reduce launch; for the fused step (`st` given) its extra workgroups also commit the step's per-position
+// results to the caller's arrays and, with `sort`, place every row in the next step's env order.
 static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStream_t s,
-                         const int32_t *next_order_ids = nullptr) {
+                         const StepArgs *st = nullptr, bool sort = false, bool reduce = true) {
     ReduceArgs R;
+    memset(&R, 0, sizeof(R));
     R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
     R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
-    // the next step's env order rides along as extra workgroups of the same launch
-    const int nrow = next_order_ids ? (c->cfg.n_envs + 255) / 256 : 0;
-    R.option_id = next_order_ids; R.perm = c->d_perm;
-    R.hist = c->d_hist2[c->hist_parity]; R.hist_zero = c->d_hist2[c->hist_parity ^ 1];
+    const int nrow = st ? (c->cfg.n_envs + 255) / 256 : 0;
     R.n = c->cfg.n_envs; R.nrow = nrow;
-    const int sy = (nrow + RED_NCOL * RED_WAVES - 1) / (RED_NCOL * RED_WAVES);
+    if (st) {
+        R.outrec = c->d_outrec; R.invperm = c->d_invperm; R.perm = c->d_perm; R.sort = sort ? 1 : 0;
+        R.hist = c->d_hist2[c->hist_parity]; R.hist_zero = c->d_hist2[c->hist_parity ^ 1];
+        R.x = st->x; R.y = st->y; R.vx = st->vx; R.vy = st->vy; R.reward = st->reward;
+        R.option_id_out = st->option_id; R.opt_steps = st->opt_steps; R.ep_steps = st->ep_steps;
+        R.action = st->action; R.done = st->done;
+    }
+    if (!reduce) {                                       // acting-only step: the commit alone
+        hipLaunchKernelGGL(commit_kernel, dim3((nrow + 3) / 4), dim3(256), 0, s, R);
+        SCG_HIP(c, hipGetLastError());
+        return SCG_OK;
+    }
+    const int sy = (nrow + RED_NCOL - 1) / RED_NCOL;
     hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
@@ -1299,7 +1361,6 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     A.n = c->cfg.n_envs; A.k_lo = 0; A.k_hi = c->n_vf - 1;
     A.enabled = enabled_mask; A.learn = (flags & SCG_STEP_LEARN) ? 1u : 0u; A.t = t;
     if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
-    A.diag = (flags >> 12) & 0xfu;       // diagnostic only: early exits for phase timing
     // env order of this step (SPEC §5): counting sort by the option ids the previous step left
     // A learning step computes the NEXT step's order inside its reduce launches; the stand-alone sort runs only
     // when that order is missing or was invalidated (first step, other array, scg_invalidate_order).
@@ -1307,7 +1368,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
         const int nrow = (c->cfg.n_envs + 255) / 256;    // the sort works on rows of 256 envs whatever the workgroup size
         hipLaunchKernelGGL(sort_hist_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, c->d_hist);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(nrow), dim3(256), 0, s, option_id, c->cfg.n_envs, c->n_vf, nrow,
-                           c->d_hist, c->d_perm);
+                           c->d_hist, c->d_perm, c->d_invperm);
         SCG_HIP(c, hipGetLastError());
     }
     c->order_valid = false;
@@ -1319,7 +1380,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     }
     const bool fold = (flags & SCG_STEP_LEARN) && !(flags & 0x200u);      // 0x200: diagnostic, sort afresh every step
     A.hist_next = fold ? c->d_hist2[c->hist_parity] : nullptr;
-    A.perm = c->d_perm;
+    A.perm = c->d_perm; A.outrec = c->d_outrec;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof_on && (c->prof_seen++ % c->prof_every) == 0) {
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
@@ -1335,15 +1396,15 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     hipLaunchKernelGGL(td_kernel<MODE_FUSED>, dim3(c->nblk), dim3(THREADS), LDS_BYTES, s, A);
     SCG_HIP(c, hipGetLastError());
     if (ev1) SCG_HIP(c, hipEventRecord(ev1, s));
-    if (flags & SCG_STEP_LEARN) {
-        if (!fold) return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s);
-        c->hist_dirty = true;                      // until the reduce launch has consumed and re-armed the counts
-        const int rc = launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s, option_id);
-        if (rc != SCG_OK) return rc;
-        c->hist_dirty = false;
-        c->hist_parity ^= 1;
-        c->order_valid = true; c->order_ids = option_id;
-    }
+    // results reach the caller's arrays through the commit workgroups of the reduce launch (or a commit launch)
+    if (!(flags & SCG_STEP_LEARN)) return launch_reduce(c, W, 0u, c->nblk, s, &A, false, false);
+    if (!fold) return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s, &A, false);
+    c->hist_dirty = true;                          // until the reduce launch has consumed and re-armed the counts
+    const int rc = launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s, &A, true);
+    if (rc != SCG_OK) return rc;
+    c->hist_dirty = false;
+    c->hist_parity ^= 1;
+    c->order_valid = true; c->order_ids = option_id;
     return SCG_OK;
 }
 
