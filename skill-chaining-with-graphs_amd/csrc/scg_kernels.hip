@@ -831,11 +831,12 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
     __shared__ float4 s_T[RED_WAVES][64];
     __shared__ int s_cnt[RED_WAVES];
-    const int sy = (int)gridDim.y - R.n_vf;              // leading workgroups: one env row per wave (dispatched first:
-    const int k = (int)blockIdx.y - sy;                  // their chain of dependent accesses is the launch's long pole)
+    // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
+    const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
+    const int rowy = (int)blockIdx.y - R.n_vf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k < 0) {
-        const int row = (int)blockIdx.y * (int)gridDim.x + blockIdx.x;      // one row per workgroup (wave 0): a row
+        const int row = rowy * (int)gridDim.x + blockIdx.x;                 // one row per workgroup (wave 0): a row
         if (wave == 0 && row < R.nrow) commit_and_place_row(R, row);        // moves ~25 KB, so spread them over the CUs
         return;
     }
@@ -846,6 +847,13 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     const int nseg = (R.nblk + SEG - 1) / SEG;
     float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int nk = 0;
+    // wave 0 applies the update at the end: fetch its W and scale columns now, under the slab loads
+    float4 *wp = reinterpret_cast<float4 *>(R.W) + (size_t)k * RED_COLS + (live ? i4 : 0);
+    float4 w_old = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sc = w_old;
+    if (wave == 0 && R.apply) {
+        w_old = *wp;
+        sc = *reinterpret_cast<const float4 *>(R.scale + ((live ? i4 : 0) * 4) % NF);     // NF % 4 == 0: no row straddling
+    }
     for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES) {
         const int b0 = (sg0 + wave) * SEG;
         const int bl = b0 + lane;
@@ -888,10 +896,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     reinterpret_cast<float4 *>(R.G)[(size_t)k * RED_COLS + i4] = S;
     if (R.apply && nk > 0) {
         const float step = R.alpha / (float)nk;
-        const int f = (i4 * 4) % NF;                                       // NF % 4 == 0: no row straddling
-        const float4 sc = *reinterpret_cast<const float4 *>(R.scale + f);
-        float4 *wp = reinterpret_cast<float4 *>(R.W) + (size_t)k * RED_COLS + i4;
-        float4 w = *wp;
+        float4 w = w_old;
         w.x = fmaf(step * sc.x, S.x, w.x); w.y = fmaf(step * sc.y, S.y, w.y);
         w.z = fmaf(step * sc.z, S.z, w.z); w.w = fmaf(step * sc.w, S.w, w.w);
         *wp = w;
