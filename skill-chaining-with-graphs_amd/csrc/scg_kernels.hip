@@ -430,6 +430,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             continue;
         }
         block_lds_sync();
+        SCG_STAMP(k == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
         // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 256 envs:
         //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), env order
         //   update lists: envs that update VF k, one run per action a_t, env order inside a run

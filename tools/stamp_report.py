@@ -25,8 +25,8 @@ for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
 out = np.zeros((nblk, 16), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
-names = ["phase P", "root: phaseZ+lists", "root: W staging", "root: loop A", "root: wait A", "root: loop B", "root: loop C",
-         "root: reduce+slab", "opt: lists", "opt: W staging", "opt: loop A", "opt: wait A", "opt: loop B", "opt: loop C", "opt: reduce+slab", "-"]
+names = ["phase P", "root: phaseZ+lists", "root: W staging", "root: loop A", "root: wait A", "root: barrier at pass start", "root: loop C",
+         "root: reduce+slab", "opt: lists", "opt: W staging", "opt: loop A", "opt: wait A", "opt: barrier at pass start", "opt: loop C", "opt: reduce+slab", "-"]
 mean = out.astype(np.float64).mean(0) / args.steps
 tot = mean.sum()
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
