@@ -57,6 +57,15 @@ def flops_per_item(evaluated: bool, updated: bool) -> float:
     return f
 
 
+# BASELINE.json's metric, verbatim (the file travels with the repo; the literal is the fallback)
+METRIC = "env-steps/sec (whole node), 65\u202f536 parallel Pinball envs at 1/2/4/8 MI355X"
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as _f:
+        METRIC = json.load(_f).get("metric", METRIC)
+except (OSError, ValueError):
+    pass
+
+
 def measured_traffic(envs_per_gpu, n_options):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate passes; profiles/r01_traffic.json) — only when it was taken on this exact workload."""
@@ -205,7 +214,7 @@ def main():
         units = n_local
         achieved = units * BYTES_PER_ENV_STEP / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": "env-steps/sec (whole node), 65536 parallel Pinball envs per MI355X, full skill chain",
+            "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
