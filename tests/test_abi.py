@@ -57,3 +57,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "sc_oracle" not in src and "oracle/" not in src, os.path.join(dp, f)
+
+
+def test_every_ctx_entry_point_rejects_a_null_ctx(pkg):
+    """Host-side argument checks come before any HIP call: with a null ctx every entry point returns
+    SCG_ERR_INVALID and leaves a message behind (runs without a GPU)."""
+    from skill_chaining_with_graphs_amd import _lib
+    lib = pkg.load_library()
+    skip = {"scg_abi_version", "scg_block_envs", "scg_strerror", "scg_last_error", "scg_create", "scg_destroy"}
+    for name, (res, args) in _lib._SIGS.items():
+        if name in skip:
+            continue
+        assert args and args[0] is C.c_void_p, name
+        zeros = [None if (a is C.c_void_p or hasattr(a, "contents")) else a(0) for a in args]
+        assert getattr(lib, name)(*zeros) == -1, name
+        assert lib.scg_last_error(None), name
