@@ -121,3 +121,32 @@ def test_quarter_million_envs_single_gpu():
     assert m.free_mask(np.stack([xs, ys], 1)[::64], margin=0.0).all()
     opt = st_d.option_id.cpu().numpy()
     assert opt.min() >= 0 and opt.max() <= NOPT and len(np.unique(opt)) >= 3
+
+
+def test_more_than_256_workgroups_bit_exact():
+    """70 000 envs = 274 workgroups = 18 first-level segments: the reduce launch needs a second round of
+    segments and the row placement a second stride over the count table — bit-exact against the oracle."""
+    n, steps = 70000, 3
+    import skill_chaining_with_graphs_amd as scg
+    m0 = scg.load_map("pinball_simple")
+    rng = np.random.default_rng(21)
+    pos = m0.sample_free(n, rng)
+    v = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=NOPT, seed=8, enabled_mask=MASK, max_episode_steps=40)
+    st_o = sc_oracle.new_state(n, m)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = pos[:, 0], pos[:, 1], v[0], v[1]
+    st_o["ep_steps"][:] = rng.integers(0, 39, n)
+    W_o = random_weights(NOPT + 1, 4, std=0.02)
+    clf = chain_classifiers(m, NOPT)
+    st_d = state_to_device(st_o, ctx)
+    W_d, clf_d = dev(W_o.copy()), dev(clf)
+    G_d, n_d = ctx.grad_buffers()
+    for t in range(steps):
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        orc.apply(W_o, G, n_k)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), MASK, t)
+        for k in ("x", "y", "vx", "vy", "option_id", "opt_steps", "ep_steps", "action", "done", "reward", "qcache"):
+            assert np.array_equal(getattr(st_d, k).cpu().numpy().reshape(-1), st_o[k].reshape(-1)), (k, t)
+        assert np.array_equal(n_d.cpu().numpy(), n_k) and np.array_equal(G_d.cpu().numpy(), G), t
+        assert np.array_equal(W_d.cpu().numpy(), W_o), t
+    assert n_k[1:].sum() > 0
