@@ -81,43 +81,51 @@ def measured_traffic(envs_per_gpu, n_options):
 
 
 def cpu_baseline(seconds_target=15.0):
-    """Time the CPU oracle on a bounded sample of the same workload (same map, options, hyper-params)."""
+    """Time the CPU oracle on a bounded sample of the same workload (same map, options, hyper-params): first
+    one thread (a third of the budget), then all host cores (SURVEY §8d asks for both)."""
     import numpy as np
     import sc_oracle
     import skill_chaining_with_graphs_amd as scg
     from skill_chaining_with_graphs_amd.core import fourier_scale_table
     cores = min(os.cpu_count() or 1, 16)
-    n = 256 * cores                       # one 256-env block per thread
     m = scg.load_map(MAP)
-    orc = sc_oracle.Oracle(m, fourier_scale_table(), n_envs=n, n_options=N_OPTIONS, seed=0,
-                           enabled_mask=sum(1 << k for k in range(1, N_OPTIONS + 1)), n_threads=cores, **HP)
     clf = chain_discs(m, N_OPTIONS)
-    st = sc_oracle.new_state(n, m)
-    rng = np.random.default_rng(0)
-    pos = m.sample_free(n, rng)
-    st["x"][:], st["y"][:] = pos[:, 0], pos[:, 1]
-    v = rng.uniform(-1, 1, (2, n)).astype(np.float32)
-    st["vx"][:], st["vy"][:] = v[0], v[1]
-    W = (rng.standard_normal((N_OPTIONS + 1, 5, 1296)) * 1e-3).astype(np.float32)
-    G, nk = orc.step(st, W, clf, 0)       # warm-up
-    orc.apply(W, G, nk)
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < seconds_target and steps < 100000:
-        G, nk = orc.step(st, W, clf, steps + 1)
+
+    def timed(threads, budget):
+        n = 256 * threads                     # one 256-env block per thread
+        orc = sc_oracle.Oracle(m, fourier_scale_table(), n_envs=n, n_options=N_OPTIONS, seed=0,
+                               enabled_mask=sum(1 << k for k in range(1, N_OPTIONS + 1)), n_threads=threads, **HP)
+        st = sc_oracle.new_state(n, m)
+        rng = np.random.default_rng(0)
+        pos = m.sample_free(n, rng)
+        st["x"][:], st["y"][:] = pos[:, 0], pos[:, 1]
+        v = rng.uniform(-1, 1, (2, n)).astype(np.float32)
+        st["vx"][:], st["vy"][:] = v[0], v[1]
+        W = (rng.standard_normal((N_OPTIONS + 1, 5, 1296)) * 1e-3).astype(np.float32)
+        G, nk = orc.step(st, W, clf, 0)       # warm-up
         orc.apply(W, G, nk)
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, OpenMP over 256-env blocks), {n} envs x {steps} "
-                      f"step-batches of the same workload in {dt:.1f} s; the upstream reference ships no code to time"}
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < budget and steps < 100000:
+            G, nk = orc.step(st, W, clf, steps + 1)
+            orc.apply(W, G, nk)
+            steps += 1
+        dt = time.perf_counter() - t0
+        return n * steps / dt, n, steps, dt
+
+    v1, n1, s1, d1 = timed(1, seconds_target / 3.0)
+    vc, nc, sc, dc = timed(cores, seconds_target * 2.0 / 3.0)
+    return {"value": vc, "unit": "env-steps/s", "cores": cores, "kind": "port", "single_thread_value": v1,
+            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, OpenMP over 256-env blocks), same workload: "
+                      f"{nc} envs x {sc} step-batches on {cores} threads in {dc:.1f} s; {n1} envs x {s1} step-batches "
+                      f"on 1 thread in {d1:.1f} s; the upstream reference ships no code to time"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--options", type=int, default=N_OPTIONS)
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
