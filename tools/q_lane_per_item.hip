@@ -11,6 +11,9 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int NF = 1296, NACT = 5;
+#ifndef PIPELINED
+#define PIPELINED 0
+#endif
 
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) { return (v2f){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 
@@ -49,6 +52,52 @@ __global__ __launch_bounds__(512, 2) void q_kernel(const float *__restrict__ W, 
     for (int r = 0; r < reps; ++r) {
 #pragma unroll
         for (int a = 0; a < NACT; ++a) q[a] = (v2f){0.0f, 0.0f};
+#if PIPELINED
+        // chunks of 6 adjacent features x 5 actions = 30 scalars; the next chunk's scalar loads are issued before
+        // the current chunk's 21 packed ops (double-buffered SGPR sets)
+        const int ch0 = half * 108;                                        // 18 c12 values x 6 chunks
+        float wn[NACT][6];
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) wn[a][u] = W[a * NF + ch0 * 6 + u];
+        }
+        for (int c12 = half * 18; c12 < half * 18 + 18; ++c12) {          // wave-uniform
+            const int c1 = c12 / 6, c2 = c12 - 6 * c1;
+            v2f z0 = Z[0][0], z1 = Z[1][0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) { if (c1 == k) z0 = Z[0][k]; if (c2 == k) z1 = Z[1][k]; }
+            const v2f ab = cmul(z0, z1);
+            const v2f abre = {ab.x, ab.x}, abim = {-ab.y, -ab.y};
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                float wc[NACT][6];
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) wc[a][u] = wn[a][u];
+                }
+                const int nxt = (c12 * 6 + m + 1 < half * 108 + 108) ? c12 * 6 + m + 1 : ch0;      // wave-uniform
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) wn[a][u] = W[a * NF + nxt * 6 + u];
+                }
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) {
+                    const int p = 3 * m + pp;
+                    const v2f phi = __builtin_elementwise_fma(abim, cdim[p], abre * cdre[p]);
+#pragma unroll
+                    for (int a = 0; a < NACT; ++a) {
+                        const v2f w = {wc[a][2 * pp], wc[a][2 * pp + 1]};
+                        q[a] = __builtin_elementwise_fma(w, phi, q[a]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#else
         for (int c12 = half * 18; c12 < half * 18 + 18; ++c12) {          // wave-uniform
             const int c1 = c12 / 6, c2 = c12 - 6 * c1;
             v2f z0 = Z[0][0], z1 = Z[1][0];
@@ -68,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void q_kernel(const float *__restrict__ W, 
             }
         }
     }
+#endif
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (half == 1) {
 #pragma unroll
