@@ -85,7 +85,8 @@ struct StepArgs {
     float *x, *y, *vx, *vy;
     int32_t *option_id, *opt_steps, *ep_steps;
     int32_t *hist_next;        // [rows of 256 envs][8] counts of the option ids this step leaves (null = off)
-    float4 *outrec;            // FUSED: [positions][2] per-env results in env-ORDER position, committed to the
+    float4 *outrec;            // FUSED: [positions][4] per-env results in env-ORDER position (one 64-byte line:
+                               // state', {reward, bits, counters}, Q(s', .) of the VF acting next), committed to the
                                // caller's arrays by commit_row (coalesced) instead of 4-byte scatters from here
     float *qcache;                 // [5][n]  (QVAL: output q)
     uint8_t *action;               // FUSED: out; TRANS: in
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 // from ~6 workgroups on different XCDs: ≈ 9 us of partial-line writes per step.)
                 {
                     const int osn = keep ? osteps + 1 : 0, epn = dn ? 0 : eps1;
-                    float4 *orec = A.outrec + (size_t)(e0 + i) * 2;
+                    float4 *orec = A.outrec + (size_t)(e0 + i) * 4;
                     orec[0] = make_float4(nx, ny, nvx, nvy);
                     orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
                                           __int_as_float(osn), __int_as_float(epn));
@@ -573,8 +574,14 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         const bool okl = gl == 0 ? ok[0] : gl == 1 ? ok[1] : gl == 2 ? ok[2] : ok[3];
                         if (lane < GI && okl) {
                             if (s_on[il] == k) {
+                                if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
+                                    float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                                    orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                                    orec[3].x = qo[4];
+                                } else {
 #pragma unroll
-                                for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
+                                    for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
+                                }
                             }
                             float mx = qo[0];
 #pragma unroll
@@ -740,6 +747,7 @@ struct ReduceArgs {
     float *x, *y, *vx, *vy, *reward;
     int32_t *option_id_out, *opt_steps, *ep_steps;
     uint8_t *action, *done;
+    float *qcache;                 // [5][n], null = the step ran no TD pass (diagnostic): leave it alone
     int32_t sort;
 };
 
@@ -756,8 +764,8 @@ __device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, 
 }
 
 // One wave per row of 256 envs (no LDS, no barriers), two dependent memory round trips in all:
-//   commit: gather each env's result record from its position in the current order (one 32-byte read) and write
-//           the caller's SoA arrays with full-line stores;
+//   commit: gather each env's result line from its position in the current order (one 64-byte read) and write
+//           the caller's SoA arrays (state, outputs, qcache) with full-line stores;
 //   sort  : place the row in the stable counting-sort order of the next step (7 keys), from the per-row key
 //           counts of all rows: offset(key k, row) = (envs with a smaller key) + (key-k envs of earlier rows).
 // Load order matters: positions first, then the count table, then the records, so that the table's latency hides
@@ -783,11 +791,12 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
             }
         }
     }
-    float4 ra[4], rb[4];
+    float4 ra[4], rb[4], rq[4];
+    float q4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float4 *r = R.outrec + (size_t)pos_old[j] * 2;
-        ra[j] = r[0]; rb[j] = r[1];
+        const float4 *r = R.outrec + (size_t)pos_old[j] * 4;
+        ra[j] = r[0]; rb[j] = r[1]; rq[j] = r[2]; q4[j] = r[3].x;
     }
     int off[7];
     if (R.sort) {
@@ -810,6 +819,11 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
             R.x[e] = ra[j].x; R.y[e] = ra[j].y; R.vx[e] = ra[j].z; R.vy[e] = ra[j].w;
             R.reward[e] = rb[j].x; R.action[e] = (uint8_t)(bits & 255u); R.done[e] = (uint8_t)((bits >> 8) & 255u);
             R.option_id_out[e] = key; R.opt_steps[e] = __float_as_int(rb[j].z); R.ep_steps[e] = __float_as_int(rb[j].w);
+            if (R.qcache) {
+                const size_t n = (size_t)R.n;
+                R.qcache[e] = rq[j].x; R.qcache[n + e] = rq[j].y; R.qcache[2 * n + e] = rq[j].z;
+                R.qcache[3 * n + e] = rq[j].w; R.qcache[4 * n + e] = q4[j];
+            }
         }
         if (R.sort) {
             int pos = -1;
@@ -1114,7 +1128,7 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
-    float4 *d_outrec;              // [nblk * BLOCK_ENVS][2] per-position step results (td_kernel -> commit_row)
+    float4 *d_outrec;              // [nblk * BLOCK_ENVS][4] per-position step results (td_kernel -> commit_row)
     int32_t *d_invperm;            // [n_envs] position of each env in d_perm
     int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
     int hist_parity;
@@ -1207,7 +1221,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipMalloc(&c->d_outrec, (size_t)c->nblk * BLOCK_ENVS * 2 * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_outrec, (size_t)c->nblk * BLOCK_ENVS * 4 * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_invperm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         {
             const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * 8 * sizeof(int32_t);
@@ -1337,6 +1351,7 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
         R.x = st->x; R.y = st->y; R.vx = st->vx; R.vy = st->vy; R.reward = st->reward;
         R.option_id_out = st->option_id; R.opt_steps = st->opt_steps; R.ep_steps = st->ep_steps;
         R.action = st->action; R.done = st->done;
+        R.qcache = st->k_hi >= 0 ? st->qcache : nullptr;
     }
     if (!reduce) {                                       // acting-only step: the commit alone
         hipLaunchKernelGGL(commit_kernel, dim3((nrow + 3) / 4), dim3(256), 0, s, R);
