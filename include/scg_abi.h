@@ -94,6 +94,12 @@ int scg_grad_buffers(scg_ctx *ctx, float **G, int32_t **n_k);
 int scg_set_grad_buffers(scg_ctx *ctx, float *G, int32_t *n_k);
 /* Apply (possibly all-reduced) G / n_k to W: W_k += alpha/n_k * scale * G_k (SPEC §5). */
 int scg_apply_update(scg_ctx *ctx, float *W, const float *G, const int32_t *n_k, void *stream);
+/* The same pair as ONE all-reduce operand: G_packed holds n_vf*6480 floats of G followed by n_vf floats that
+ * receive the update counts as floats (exact: they stay far below 2^24), so a sharded run with shared weights
+ * sums (G, n_k) over the ranks with a single latency-bound collective per step. NULL restores the ctx-owned
+ * buffers. scg_apply_update_packed reads the counts back from the tail. */
+int scg_set_grad_buffer_packed(scg_ctx *ctx, float *G_packed);
+int scg_apply_update_packed(scg_ctx *ctx, float *W, const float *G_packed, void *stream);
 
 /* ---- un-fused entry points (same arithmetic; used by the API facade and the parity tests) ---- */
 

@@ -56,6 +56,8 @@ _SIGS = {
     "scg_grad_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "scg_set_grad_buffers": (C.c_int, [_P, _P, _P]),
     "scg_apply_update": (C.c_int, [_P, _P, _P, _P, _P]),
+    "scg_set_grad_buffer_packed": (C.c_int, [_P, _P]),
+    "scg_apply_update_packed": (C.c_int, [_P, _P, _P, _P]),
     "scg_pinball_step": (C.c_int, [_P, C.c_int32] + [_P] * 7 + [_P]),
     "scg_fourier_features": (C.c_int, [_P, C.c_int32] + [_P] * 5 + [_P]),
     "scg_q_values": (C.c_int, [_P, C.c_int32] + [_P] * 6 + [_P]),

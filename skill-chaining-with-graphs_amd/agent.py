@@ -135,18 +135,17 @@ class SkillChainingAgent:
         """One fused step-batch over all envs (act, physics, options, features, Q, TD, update)."""
         shared = self.group is not None and learn
         if shared:
-            G, n_k = self.ctx.grad_buffers()
+            gp = self.ctx.grad_packed()                  # G and the update counts: ONE all-reduce operand
         self.ctx.step(self.state, self.W, self.clf, self.enabled_mask, self.t, learn=learn, apply=not shared)
         if shared:
             import torch.distributed as dist
             if dist.get_backend(self.group) == "gloo":  # CPU rehearsal of the N>1 path: stage through the host
-                Gc, nc = G.cpu(), n_k.cpu()
-                dist.all_reduce(Gc, group=self.group); dist.all_reduce(nc, group=self.group)
-                G.copy_(Gc); n_k.copy_(nc)
+                gc = gp.cpu()
+                dist.all_reduce(gc, group=self.group)
+                gp.copy_(gc)
             else:
-                dist.all_reduce(G, group=self.group)    # RCCL over xGMI: one fused 26 KB x n_vf message
-                dist.all_reduce(n_k, group=self.group)
-            self.ctx.apply_update(self.W, G, n_k)
+                dist.all_reduce(gp, group=self.group)   # RCCL over xGMI: one latency-bound 26 KB x n_vf message
+            self.ctx.apply_update_packed(self.W, gp)
         self.t += 1
 
     def q_update(self, k: int, s, action, r, cont, s_next, apply: bool = True) -> None:

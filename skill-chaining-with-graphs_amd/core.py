@@ -172,7 +172,23 @@ class ScgContext:
             n = torch.zeros((self.n_vf,), dtype=torch.int32, device=self.device)
             self._call("scg_set_grad_buffers", _ptr(G), _ptr(n))
             self._gbuf = (G, n)
+            self.__dict__.pop("_gpacked", None)
         return self._gbuf
+
+    def grad_packed(self) -> torch.Tensor:
+        """One flat float32 tensor [n_vf*5*1296 + n_vf]: G followed by the update counts as floats — the single
+        all-reduce operand of a sharded run with shared weights (scg_set_grad_buffer_packed)."""
+        if not hasattr(self, "_gpacked"):
+            gp = torch.zeros(self.n_vf * NUM_ACTIONS * NUM_FEATURES + self.n_vf, dtype=torch.float32, device=self.device)
+            self._call("scg_set_grad_buffer_packed", _ptr(gp))
+            self._gpacked = gp
+            self.__dict__.pop("_gbuf", None)
+        return self._gpacked
+
+    def apply_update_packed(self, W: torch.Tensor, gp: torch.Tensor) -> None:
+        self._chk(W, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
+        self._chk(gp, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES + self.n_vf, "G_packed")
+        self._call("scg_apply_update_packed", _ptr(W), _ptr(gp), self._stream())
 
     def apply_update(self, W: torch.Tensor, G: torch.Tensor, n_k: torch.Tensor) -> None:
         self._chk(W, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")

@@ -730,6 +730,7 @@ struct ReduceArgs {
     const int32_t *cnts;
     float *G;
     int32_t *n_k;
+    float *nk_f;             // packed operand: the counts again, as floats right after G (null = off)
     float *W;
     const float *scale;
     int32_t nblk, n_vf;
@@ -906,7 +907,10 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         __syncthreads();
     }
     if (wave != 0) return;
-    if (blockIdx.x == 0 && lane == 0) R.n_k[k] = nk;
+    if (blockIdx.x == 0 && lane == 0) {
+        R.n_k[k] = nk;
+        if (R.nk_f) R.nk_f[k] = (float)nk;               // exact: counts stay far below 2^24
+    }
     if (!live) return;
     reinterpret_cast<float4 *>(R.G)[(size_t)k * RED_COLS + i4] = S;
     if (R.apply && nk > 0) {
@@ -924,12 +928,12 @@ __global__ __launch_bounds__(256) void commit_kernel(const ReduceArgs R) {
     if (row < R.nrow) commit_and_place_row(R, row);
 }
 
-__global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, const int32_t *n_k,
+__global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, const int32_t *n_k, const float *nk_f,
                                                     const float *scale, float alpha) {
     const int k = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NACT * NF) return;
-    const int nk = n_k[k];
+    const int nk = n_k ? n_k[k] : (int)(nk_f[k] + 0.5f);     // packed operand: counts summed as floats (exact)
     if (nk <= 0) return;
     const float step = alpha / (float)nk;
     const int f = i % NF;
@@ -1147,6 +1151,7 @@ struct scg_ctx {
     int32_t *d_nk;
     float *G_out;          // where reduce leaves G / n_k (ctx-owned by default)
     int32_t *nk_out;
+    float *nkf_out;        // packed operand: float copy of the counts right after G (null = off)
     bool prof_on;          // measurement hook: event pairs round the fused kernel
     int prof_every;        // ... of every prof_every-th launch (events cost a few us of queue bubble each)
     long long prof_seen;
@@ -1341,7 +1346,7 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
                          const StepArgs *st = nullptr, bool sort = false, bool reduce = true) {
     ReduceArgs R;
     memset(&R, 0, sizeof(R));
-    R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.W = W; R.scale = c->d_scale;
+    R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.nk_f = c->nkf_out; R.W = W; R.scale = c->d_scale;
     R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
     const int nrow = st ? (c->cfg.n_envs + 255) / 256 : 0;
     R.n = c->cfg.n_envs; R.nrow = nrow;
@@ -1522,6 +1527,25 @@ int scg_set_grad_buffers(scg_ctx *c, float *G, int32_t *n_k) {
         return fail(c, SCG_ERR_INVALID, "scg_set_grad_buffers: pass both buffers or neither");
     c->G_out = G ? G : c->d_G;
     c->nk_out = n_k ? n_k : c->d_nk;
+    c->nkf_out = nullptr;
+    return SCG_OK;
+}
+
+int scg_set_grad_buffer_packed(scg_ctx *c, float *G_packed) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_grad_buffer_packed: null ctx");
+    c->G_out = G_packed ? G_packed : c->d_G;
+    c->nk_out = c->d_nk;
+    c->nkf_out = G_packed ? G_packed + (size_t)c->n_vf * NACT * NF : nullptr;
+    return SCG_OK;
+}
+
+int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *stream) {
+    if (!c || !W || !G_packed) return fail(c, SCG_ERR_INVALID, "scg_apply_update_packed: null argument");
+    if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update_packed: scg_set_map has not been called (scale table)");
+    dim3 grid((NACT * NF + 255) / 256, c->n_vf);
+    hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G_packed,
+                       (const int32_t *)nullptr, G_packed + (size_t)c->n_vf * NACT * NF, c->d_scale, c->cfg.alpha);
+    SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
 
@@ -1530,7 +1554,7 @@ int scg_apply_update(scg_ctx *c, float *W, const float *G, const int32_t *n_k, v
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update: scg_set_map has not been called (scale table)");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G, n_k,
-                       c->d_scale, c->cfg.alpha);
+                       (const float *)nullptr, c->d_scale, c->cfg.alpha);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }

@@ -195,6 +195,31 @@ def test_env_order_prepared_by_the_previous_step_and_invalidated_on_outside_writ
     assert n_k[1:].sum() > 0
 
 
+def test_packed_gradient_operand_matches_the_split_pair():
+    """scg_set_grad_buffer_packed: G and the counts (as floats) in one buffer — the single all-reduce operand of
+    the shared-weights path — and scg_apply_update_packed give the same W as LEARN|APPLY."""
+    n, n_options, mask = 1300, 2, 0b110
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=n_options, seed=3, enabled_mask=mask)
+    clf = chain_classifiers(m, n_options)
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 17, vmax=1.0)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    W_o = random_weights(3, 15, std=0.05)
+    st_d = state_to_device(st_o, ctx)
+    W_d, clf_d = dev(W_o.copy()), dev(clf)
+    gp = ctx.grad_packed()
+    for t in range(4):
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        orc.apply(W_o, G, n_k)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), mask, t, learn=True, apply=False)
+        flat = gp.cpu().numpy()
+        assert np.array_equal(flat[:G.size].reshape(G.shape), G)
+        assert np.array_equal(flat[G.size:], n_k.astype(np.float32))
+        ctx.apply_update_packed(W_d.view(-1), gp)
+        assert np.array_equal(W_d.cpu().numpy(), W_o), t
+    assert n_k[1:].sum() > 0
+
+
 def test_host_checks_fail_before_any_launch():
     from skill_chaining_with_graphs_amd import ScgError
     ctx, orc, m = make_pair("pinball_simple", 64)
