@@ -97,6 +97,7 @@ static void state_features(float x, float y, float vx, float vy, float *phi) {
 /* ------------------------------------------------------------------ SPEC §3.1: canonical wave order */
 int sco_feature_index(int lane, int slot) {
     if (lane < 0 || lane >= NLANE || slot < 0 || slot >= NSLOT) return -1;
+    if (slot < 16) return (8 * (slot >> 2) + 4 * (lane >> 5) + (slot & 3)) * 36 + (lane & 31);
     if (slot < 18) return (2 * slot + (lane >> 5)) * 36 + (lane & 31);
     int idx = 64 * (slot - 18) + lane;
     if (idx >= 144) return -1;

@@ -317,12 +317,14 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 
     // scratch tables: per wave 2 buffers x 72 entries (AB 0..35, CD 36..71) x {x[4 items], y[4 items]}
     float *scr0 = s_scr + wave * SCR_WAVE_FLOATS;
-    const float4 *t_m0 = reinterpret_cast<const float4 *>(scr0) + 2 * hi;                    // [4j], [4j+1]
+    const float4 *t_m0 = reinterpret_cast<const float4 *>(scr0) + 2 * hi;                    // slots 16, 17: [4j], [4j+1]
+    const float4 *t_q0 = reinterpret_cast<const float4 *>(scr0) + 8 * hi;                    // slots 0..15: entry 8(j>>2) + 4 hi + (j&3)
     const float4 *t_t0 = reinterpret_cast<const float4 *>(scr0) + 2 * tl;                    // [32t], [32t+1]
     const float4 *t_t20 = reinterpret_cast<const float4 *>(scr0) + 2 * min(32 + tl, 35);
     const float4 *t_cm0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + col);
     const float4 *t_ct0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + 32 + (lane & 3));
-    float *buf_m = s_buf + hi * 36 + col;                 // buf_m[a*NF + 72j]
+    float *buf_m = s_buf + hi * 36 + col;                 // slots 16, 17: buf_m[a*NF + 72j]
+    float *buf_q = s_buf + hi * 144 + col;                // slots 0..15: buf_q[a*NF + 36 (8(j>>2) + (j&3))]
     float *buf_t = s_buf + tl * 36 + 32 + (lane & 3);     // buf_t[a*NF + 576t]
 
     // table building: lane l owns entry l (round 0) and, for l < 8, entry 64 + l (round 1) of all 4 items.
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
     };
 
-    const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets of the lane's main / tail slots
+    const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets of the lane's slots 16-17 / 0-15 / tail
+    const uint32_t w_vq = (uint32_t)(hi * 144 + col) * 4u;
     const uint32_t w_vt = (uint32_t)(tl * 36 + 32 + (lane & 3)) * 4u;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(A.W), 0, (MODE == MODE_QVAL ? 1 : A.n_vf) * NACT * NF * 4, 0x00020000);
@@ -383,8 +386,9 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     } while (0)
 
 // table reads of slot J (compile-time J): x[4] / y[4] of the slot's AB entry
-#define SCG_LDX(J) ((J) < 18 ? t_m[4 * (J)] : ((J) < 20 ? t_t[32 * ((J)-18)] : t_t2[0]))
-#define SCG_LDY(J) ((J) < 18 ? t_m[4 * (J) + 1] : ((J) < 20 ? t_t[32 * ((J)-18) + 1] : t_t2[1]))
+#define SCG_QOFF(J) (8 * ((J) >> 2) + ((J) & 3))              /* slots 0..15 (SPEC §3.1): c12 = SCG_QOFF(j) + 4 hi */
+#define SCG_LDX(J) ((J) < 16 ? t_q[2 * SCG_QOFF(J)] : (J) < 18 ? t_m[4 * (J)] : ((J) < 20 ? t_t[32 * ((J)-18)] : t_t2[0]))
+#define SCG_LDY(J) ((J) < 16 ? t_q[2 * SCG_QOFF(J) + 1] : (J) < 18 ? t_m[4 * (J) + 1] : ((J) < 20 ? t_t[32 * ((J)-18) + 1] : t_t2[1]))
 // The slot loop shared by loops A, B and C: for j = 0..20 form phi of the quad's 4 items (pa = items 0,1;
 // pb = items 2,3; packed fp32) from the tables at t_m/t_t/t_t2 and the lane's column factors, then run BODY.
 // Table reads are register-pipelined DEPTH slots ahead and sched_barrier pins that pattern (left alone,
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     wave_lds_sync();                                                                                    \
     load_group(LST, CNT, 4 * ((QN) < (NQ) ? (QN) : qi), ne, nok);                                       \
     if ((QN) < (NQ)) gen_tables(ne, SG, scr0 + TAB_FLOATS - boff * 4);                                  \
-    const float4 *t_m = t_m0 + boff, *t_t = t_t0 + boff, *t_t2 = t_t20 + boff;                          \
+    const float4 *t_m = t_m0 + boff, *t_q = t_q0 + boff, *t_t = t_t0 + boff, *t_t2 = t_t20 + boff;                          \
     float4 ccx = t_cm0[boff], ccy = t_cm0[boff + 1];          /* the lane's main column factor (slots 0..17) */
 #define SCG_GROUP_END                                                                                   \
     _Pragma("unroll") for (int g = 0; g < GI; ++g) { ie[g] = ne[g]; ok[g] = nok[g]; }                   \
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-                for (int j = 0; j < 18; ++j) SCG_R_SET(a, j, buf_m[a * NF + 72 * j]);
+                for (int j = 0; j < 18; ++j) SCG_R_SET(a, j, j < 16 ? buf_q[a * NF + 36 * SCG_QOFF(j)] : buf_m[a * NF + 72 * j]);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const float v = buf_t[a * NF + 576 * t];       // lanes >= 16 read a neighbour's weight at t = 2
@@ -525,7 +529,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 #pragma unroll
                 for (int j = 0; j < 18; ++j)
                     SCG_R_SET(a, j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                                        w_rsrc, w_vm, kb + (uint32_t)(a * NF + 72 * j) * 4u, 0)));
+                                        w_rsrc, j < 16 ? w_vq : w_vm,
+                                        kb + (uint32_t)(a * NF + (j < 16 ? 36 * SCG_QOFF(j) : 72 * j)) * 4u, 0)));
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
@@ -624,7 +629,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 float v;
                 if (j < 18) {
                     v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        w_rsrc, w_vm, kbase + (uint32_t)(AA * NF + 72 * j) * 4u, 0));
+                        w_rsrc, j < 16 ? w_vq : w_vm,
+                        kbase + (uint32_t)(AA * NF + (j < 16 ? 36 * SCG_QOFF(j) : 72 * j)) * 4u, 0));
                 } else {
                     v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                         w_rsrc, (j < 20 || v20) ? w_vt : 0u, kbase + (uint32_t)(AA * NF + 576 * (j - 18)) * 4u, 0));
@@ -700,7 +706,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     for (int w = 1; w < WAVES; ++w) sum = sum + s_scr[w * SCR_WAVE_FLOATS + o];
                     // canonical feature index of (lane l, slot j) — SPEC §3.1
                     int f = -1;
-                    if (j < 18) f = (2 * j + (l >> 5)) * 36 + (l & 31);
+                    if (j < 16) f = (SCG_QOFF(j) + 4 * (l >> 5)) * 36 + (l & 31);
+                    else if (j < 18) f = (2 * j + (l >> 5)) * 36 + (l & 31);
                     else {
                         const int idx = 64 * (j - 18) + l;
                         if (idx < 144) f = (idx >> 2) * 36 + 32 + (idx & 3);
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         SCG_STAMP(k == 0 ? 7 : 14);   // block reduction + slab store
     }
 #undef SCG_LDX
+#undef SCG_QOFF
 #undef SCG_LDY
 #undef SCG_SLOT_LOOP
 #undef SCG_SLOT_LOOP4

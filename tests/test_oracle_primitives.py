@@ -51,7 +51,8 @@ def test_wave_order_is_a_bijection(orc):
     valid = [f for f in seen if f >= 0]
     assert sorted(valid) == list(range(1296))
     assert seen.count(-1) == 64 * 21 - 1296
-    assert orc.feature_index(0, 0) == 0 and orc.feature_index(33, 0) == 36 + 1
+    assert orc.feature_index(0, 0) == 0 and orc.feature_index(33, 0) == 4 * 36 + 1      # lane 33: upper half, col 1
+    assert orc.feature_index(2, 5) == (8 + 1) * 36 + 2 and orc.feature_index(40, 17) == 35 * 36 + 8
     assert orc.feature_index(5, 18) == 1 * 36 + 32 + 1 and orc.feature_index(16, 20) == -1
 
 
