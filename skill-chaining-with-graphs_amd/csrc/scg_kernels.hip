@@ -23,6 +23,7 @@
 #include <vector>
 
 using namespace scg;
+typedef float f16v __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
 // LDS map of the step kernel (bytes)
@@ -310,6 +311,15 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     // packed-fp32 over item pairs. Canonical orders are untouched: item -> wave by list position mod 8,
     // every dot product is one fma chain over slots 0..20 per lane, items accumulate in list order.
     constexpr int GI = 4;
+    // Optional (-DSCG_MFMA=1, `make mfma`): slots 0..15 of every item's phi from one v_mfma_f32_32x32x2_f32 per item
+    // (SPEC §3.1's slot order is that instruction's accumulator layout and its result is bit-identical to the VALU
+    // formula — tools/mfma_phi_exact.hip; the parity suite passes with it). Off by default: it removes ~22 % of the
+    // slot loops' VALU instructions, but each MFMA holds the SIMD for 64 cycles and measured 164.7 vs 157.8 us per
+    // step.
+#ifndef SCG_MFMA
+#define SCG_MFMA 0
+#endif
+    constexpr bool USE_MFMA = SCG_MFMA != 0;
     const int hi = lane >> 5, col = lane & 31;
     const int tl = lane >> 2;                             // tail row part: c12 = 16 t + tl
     const bool v20 = lane < 16;                           // slot 20 holds a feature only in lanes 0..15
@@ -319,6 +329,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     float *scr0 = s_scr + wave * SCR_WAVE_FLOATS;
     const float4 *t_m0 = reinterpret_cast<const float4 *>(scr0) + 2 * hi;                    // slots 16, 17: [4j], [4j+1]
     const float4 *t_q0 = reinterpret_cast<const float4 *>(scr0) + 8 * hi;                    // slots 0..15: entry 8(j>>2) + 4 hi + (j&3)
+    const float4 *t_a0 = reinterpret_cast<const float4 *>(scr0) + 2 * col + hi;              // MFMA A operand: AB entry col, x or y
     const float4 *t_t0 = reinterpret_cast<const float4 *>(scr0) + 2 * tl;                    // [32t], [32t+1]
     const float4 *t_t20 = reinterpret_cast<const float4 *>(scr0) + 2 * min(32 + tl, 35);
     const float4 *t_cm0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + col);
@@ -394,11 +405,11 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 // Table reads are register-pipelined DEPTH slots ahead and sched_barrier pins that pattern (left alone,
 // hipcc hoists all 42 ds_read_b128 of a quad and spills hundreds of VGPRs). Loop A is register-bound
 // (DEPTH 1); loops B and C have only ~7 instructions per slot, so they run 4 slots ahead.
-#define SCG_SLOT_LOOP_D(DEPTH, ...)                                                                     \
+#define SCG_SLOT_LOOP_DS(DEPTH, J0, ...)                                                                \
     {                                                                                                   \
         float4 axq[DEPTH + 1], ayq[DEPTH + 1];                                                          \
-        _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = SCG_LDX(d_); ayq[d_] = SCG_LDY(d_); } \
-        _Pragma("unroll") for (int j = 0; j < NSLOT; ++j) {                                             \
+        _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = SCG_LDX((J0) + d_); ayq[d_] = SCG_LDY((J0) + d_); } \
+        _Pragma("unroll") for (int j = (J0); j < NSLOT; ++j) {                                          \
             if (j + DEPTH < NSLOT) { axq[DEPTH] = SCG_LDX(j + DEPTH); ayq[DEPTH] = SCG_LDY(j + DEPTH); } \
             if (j == 18) { ccx = t_ct0[boff]; ccy = t_ct0[boff + 1]; }   /* tail column factor from here on */ \
             const float4 ax0 = axq[0], ay0 = ayq[0], cx_ = ccx, cy_ = ccy;                              \
@@ -412,18 +423,35 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             __builtin_amdgcn_sched_barrier(0);                                                          \
         }                                                                                               \
     }
-#define SCG_SLOT_LOOP(...) SCG_SLOT_LOOP_D(1, __VA_ARGS__)
-#define SCG_SLOT_LOOP4(...) SCG_SLOT_LOOP_D(2, __VA_ARGS__)
+// With USE_MFMA the slots 0..15 come from the matrix pipe (PHI, see SCG_GROUP_BEGIN) and the loop starts at slot 16.
+#define SCG_J0 (USE_MFMA ? 16 : 0)
+#define SCG_SLOT_LOOP(...) SCG_SLOT_LOOP_DS(1, SCG_J0, __VA_ARGS__)
+#define SCG_SLOT_LOOP4(...) SCG_SLOT_LOOP_DS(2, SCG_J0, __VA_ARGS__)
+#define SCG_MFMA_PAIR(H)                                                                                \
+    {                                                                                                   \
+        const f16v z_ = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; \
+        PHI[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((H) ? av_.z : av_.x, (H) ? bv_.z : bv_.x, z_, 0, 0, 0); \
+        PHI[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((H) ? av_.w : av_.y, (H) ? bv_.w : bv_.y, z_, 0, 0, 0); \
+    }
 // quad prologue: wait for this quad's tables, start the next quad's (index QN, if < NQ), bind table pointers
 #define SCG_GROUP_BEGIN(LST, CNT, QN, NQ, SG)                                                           \
     const int boff = (par & 1) * (TAB_FLOATS / 4);                                                      \
     int ne[GI];                                                                                         \
     bool nok[GI];                                                                                       \
     wave_lds_sync();                                                                                    \
+    float4 ccx = t_cm0[boff], ccy = t_cm0[boff + 1];          /* the lane's main column factor (slots 0..17) */ \
+    /* phi of slots 0..15: one MFMA per item, two items at a time (32 VGPRs); operands: AB entry `col` as      \
+       Re (lanes < 32) / -Im (lanes >= 32), CD entry `col` as Re / Im, for the quad's 4 items */           \
+    f16v PHI[2];                                                                                        \
+    float4 av_ = ccx, bv_ = ccx;                                                                        \
+    if constexpr (USE_MFMA) {                                                                           \
+        av_ = t_a0[boff];                                                                               \
+        bv_ = hi ? ccy : ccx;                                                                           \
+        SCG_MFMA_PAIR(0)                                       /* runs under the next quad's table build */ \
+    }                                                                                                   \
     load_group(LST, CNT, 4 * ((QN) < (NQ) ? (QN) : qi), ne, nok);                                       \
     if ((QN) < (NQ)) gen_tables(ne, SG, scr0 + TAB_FLOATS - boff * 4);                                  \
-    const float4 *t_m = t_m0 + boff, *t_q = t_q0 + boff, *t_t = t_t0 + boff, *t_t2 = t_t20 + boff;                          \
-    float4 ccx = t_cm0[boff], ccy = t_cm0[boff + 1];          /* the lane's main column factor (slots 0..17) */
+    const float4 *t_m = t_m0 + boff, *t_q = t_q0 + boff, *t_t = t_t0 + boff, *t_t2 = t_t20 + boff;
 #define SCG_GROUP_END                                                                                   \
     _Pragma("unroll") for (int g = 0; g < GI; ++g) { ie[g] = ne[g]; ok[g] = nok[g]; }                   \
     ++par;
@@ -553,16 +581,56 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     v2f q01[GI], q23[GI], q4a = {0.0f, 0.0f}, q4b = {0.0f, 0.0f};
 #pragma unroll
                     for (int g = 0; g < GI; ++g) { q01[g] = (v2f){0.0f, 0.0f}; q23[g] = (v2f){0.0f, 0.0f}; }
-                    SCG_SLOT_LOOP(
-                        const float ph[GI] = {pa.x, pa.y, pb.x, pb.y};
-                        _Pragma("unroll") for (int g = 0; g < GI; ++g) {
-                            const v2f p2 = {ph[g], ph[g]};                            // op_sel splat of a pair half
-                            q01[g] = __builtin_elementwise_fma(Rp[0][j], p2, q01[g]);
-                            q23[g] = __builtin_elementwise_fma(Rp[1][j], p2, q23[g]);
-                        }
-                        const v2f w4 = {SCG_R4(j), SCG_R4(j)};                        // action 4: packed over items
-                        q4a = __builtin_elementwise_fma(w4, pa, q4a);
-                        q4b = __builtin_elementwise_fma(w4, pb, q4b);)
+                    // With the matrix pipe, items go in two pairs: slots 0..15 of a pair come out of PHI (two MFMAs), and
+                    // while the second pair's MFMAs run, the first pair's slots 16..20 are done on the VALU. Every item's
+                    // chain still runs over slots 0..20 in order; the (register-limited) PHI holds one pair at a time.
+#define SCG_A_MAIN(H)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                    \
+        _Pragma("unroll") for (int gg = 0; gg < 2; ++gg) {                                              \
+            const float ph = PHI[gg][j];                                                                \
+            const v2f p2 = {ph, ph};                                                                    \
+            q01[2 * (H) + gg] = __builtin_elementwise_fma(Rp[0][j], p2, q01[2 * (H) + gg]);             \
+            q23[2 * (H) + gg] = __builtin_elementwise_fma(Rp[1][j], p2, q23[2 * (H) + gg]);             \
+            q4s[2 * (H) + gg] = fmaf(SCG_R4(j), ph, q4s[2 * (H) + gg]);                                 \
+        }                                                                                               \
+    }
+                    if constexpr (USE_MFMA) {
+                        float q4s[GI] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        SCG_A_MAIN(0)
+                        q4a = (v2f){q4s[0], q4s[1]};
+                        SCG_MFMA_PAIR(1)
+                        SCG_SLOT_LOOP(                                                  // items 0, 1 (pb is dead code here)
+                            const v2f p0 = {pa.x, pa.x}, p1 = {pa.y, pa.y};
+                            q01[0] = __builtin_elementwise_fma(Rp[0][j], p0, q01[0]);
+                            q23[0] = __builtin_elementwise_fma(Rp[1][j], p0, q23[0]);
+                            q01[1] = __builtin_elementwise_fma(Rp[0][j], p1, q01[1]);
+                            q23[1] = __builtin_elementwise_fma(Rp[1][j], p1, q23[1]);
+                            const v2f w4 = {SCG_R4(j), SCG_R4(j)};
+                            q4a = __builtin_elementwise_fma(w4, pa, q4a);)
+                        ccx = t_cm0[boff]; ccy = t_cm0[boff + 1];                       // main column factor again
+                        SCG_A_MAIN(1)
+                        q4b = (v2f){q4s[2], q4s[3]};
+                        SCG_SLOT_LOOP(                                                  // items 2, 3
+                            const v2f p2_ = {pb.x, pb.x}, p3 = {pb.y, pb.y};
+                            q01[2] = __builtin_elementwise_fma(Rp[0][j], p2_, q01[2]);
+                            q23[2] = __builtin_elementwise_fma(Rp[1][j], p2_, q23[2]);
+                            q01[3] = __builtin_elementwise_fma(Rp[0][j], p3, q01[3]);
+                            q23[3] = __builtin_elementwise_fma(Rp[1][j], p3, q23[3]);
+                            const v2f w4 = {SCG_R4(j), SCG_R4(j)};
+                            q4b = __builtin_elementwise_fma(w4, pb, q4b);)
+                    } else {
+                        SCG_SLOT_LOOP(
+                            const float ph[GI] = {pa.x, pa.y, pb.x, pb.y};
+                            _Pragma("unroll") for (int g = 0; g < GI; ++g) {
+                                const v2f p2 = {ph[g], ph[g]};                            // op_sel splat of a pair half
+                                q01[g] = __builtin_elementwise_fma(Rp[0][j], p2, q01[g]);
+                                q23[g] = __builtin_elementwise_fma(Rp[1][j], p2, q23[g]);
+                            }
+                            const v2f w4 = {SCG_R4(j), SCG_R4(j)};                        // action 4: packed over items
+                            q4a = __builtin_elementwise_fma(w4, pa, q4a);
+                            q4b = __builtin_elementwise_fma(w4, pb, q4b);)
+                    }
+#undef SCG_A_MAIN
                     float qv[GI * NACT];
 #pragma unroll
                     for (int g = 0; g < GI; ++g) {
@@ -648,11 +716,37 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 SCG_GROUP_BEGIN(lst, cnt, qi + WAVES, nq, 0)
                 const float4 cmx_ = ccx, cmy_ = ccy;                  // main column factor, needed again in pass 2
                 v2f qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
-                SCG_SLOT_LOOP4(
-                    const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
-                    const v2f w2 = {wj, wj};                              // op_sel splat of a pair half
-                    qa = __builtin_elementwise_fma(w2, pa, qa);
-                    qb = __builtin_elementwise_fma(w2, pb, qb);)
+#define SCG_B_MAIN(H)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                    \
+        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;                                         \
+        qs4[2 * (H)] = fmaf(wj, PHI[0][j], qs4[2 * (H)]);                                               \
+        qs4[2 * (H) + 1] = fmaf(wj, PHI[1][j], qs4[2 * (H) + 1]);                                       \
+    }
+                if constexpr (USE_MFMA) {
+                    float qs4[GI] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    SCG_B_MAIN(0)
+                    qa = (v2f){qs4[0], qs4[1]};
+                    SCG_MFMA_PAIR(1)
+                    SCG_SLOT_LOOP4(
+                        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
+                        const v2f w2 = {wj, wj};
+                        qa = __builtin_elementwise_fma(w2, pa, qa);)
+                    ccx = t_cm0[boff]; ccy = t_cm0[boff + 1];            // main column factor again (re-read: cheaper than 8 VGPRs)
+                    SCG_B_MAIN(1)
+                    qb = (v2f){qs4[2], qs4[3]};
+                    SCG_MFMA_PAIR(0)                                  // items 0, 1 again for pass 2, under the rest of pass 1
+                    SCG_SLOT_LOOP4(
+                        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
+                        const v2f w2 = {wj, wj};
+                        qb = __builtin_elementwise_fma(w2, pb, qb);)
+                } else {
+                    SCG_SLOT_LOOP4(
+                        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
+                        const v2f w2 = {wj, wj};                              // op_sel splat of a pair half
+                        qa = __builtin_elementwise_fma(w2, pa, qa);
+                        qb = __builtin_elementwise_fma(w2, pb, qb);)
+                }
+#undef SCG_B_MAIN
                 const float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
                 float qo[1];
                 quad_transposed_sum<1>(qs, qo, lane);                 // lane l holds Q(s,a) of item (l & 3)
@@ -669,11 +763,22 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         dl[g] = ok[g] ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), g)) : 0.0f;
                 }
                 ccx = cmx_; ccy = cmy_;
+#define SCG_C_MAIN(H)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                    \
+        Acc[AA][j] = fmaf(dl[2 * (H)], PHI[0][j], Acc[AA][j]);                                          \
+        Acc[AA][j] = fmaf(dl[2 * (H) + 1], PHI[1][j], Acc[AA][j]);                                      \
+    }
+                if constexpr (USE_MFMA) {
+                    SCG_C_MAIN(0)
+                    SCG_MFMA_PAIR(1)                                  // items 2, 3 again, under the VALU slots
+                }
                 SCG_SLOT_LOOP4(
                     Acc[AA][j] = fmaf(dl[0], pa.x, Acc[AA][j]);
                     Acc[AA][j] = fmaf(dl[1], pa.y, Acc[AA][j]);
                     Acc[AA][j] = fmaf(dl[2], pb.x, Acc[AA][j]);
                     Acc[AA][j] = fmaf(dl[3], pb.y, Acc[AA][j]);)
+                if constexpr (USE_MFMA) { SCG_C_MAIN(1) }
+#undef SCG_C_MAIN
                 SCG_GROUP_END
             }
         };
@@ -723,8 +828,10 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 #undef SCG_LDY
 #undef SCG_SLOT_LOOP
 #undef SCG_SLOT_LOOP4
-#undef SCG_SLOT_LOOP_D
+#undef SCG_SLOT_LOOP_DS
+#undef SCG_J0
 #undef SCG_GROUP_BEGIN
+#undef SCG_MFMA_PAIR
 #undef SCG_GROUP_END
 #undef SCG_R
 #undef SCG_R_SET
