@@ -377,12 +377,39 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
      * and blocks are 256 consecutive positions of that order. Every per-env array stays indexed by env. */
     int *perm = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
     {
-        int pos = 0;
-        for (int k = 0; k < n_vf; ++k)
-            for (int e = 0; e < N; ++e)
-                if (option_id[e] == k) perm[pos++] = e;
-        for (int e = 0; e < N; ++e)              /* ids outside [0, n_vf) (never produced by the step) go last */
-            if (option_id[e] < 0 || option_id[e] >= n_vf) perm[pos++] = e;
+        /* key of an env: its option id, ids outside [0, n_vf) -> n_vf (never produced by the step). Runs of the
+         * keys 1..6 follow one another in key order, envs in env order inside a run; after every non-empty run,
+         * envs of key 0 (running no option), in env order, pad the position up to the next multiple of the block
+         * size while any are left, so that a block never holds two options' runs; what remains of key 0 comes last. */
+        int tot[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < N; ++e) {
+            int o = option_id[e];
+            if (o < 0 || o >= n_vf) o = n_vf;
+            tot[o]++;
+        }
+        int base[7], pad_lo[7], pad_n[7], pad_pos[7];
+        int Pp = 0, used = 0;
+        for (int k = 1; k < 7; ++k) {
+            base[k] = Pp; Pp += tot[k];
+            int need = tot[k] > 0 ? (g_block_envs - Pp % g_block_envs) % g_block_envs : 0;
+            int pad = need < tot[0] - used ? need : tot[0] - used;
+            pad_lo[k] = used; pad_n[k] = pad; pad_pos[k] = Pp; used += pad; Pp += pad;
+        }
+        const int tail_lo = used, tail_pos = Pp;
+        int rank[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < N; ++e) {
+            int o = option_id[e];
+            if (o < 0 || o >= n_vf) o = n_vf;
+            const int r = rank[o]++;
+            int pos;
+            if (o > 0) pos = base[o] + r;
+            else {
+                pos = tail_pos + (r - tail_lo);
+                for (int k = 1; k < 7; ++k)
+                    if (r >= pad_lo[k] && r < pad_lo[k] + pad_n[k]) pos = pad_pos[k] + (r - pad_lo[k]);
+            }
+            perm[pos] = e;
+        }
     }
     float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * n_vf * NACT * NF);
     int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1) * n_vf, sizeof(int));

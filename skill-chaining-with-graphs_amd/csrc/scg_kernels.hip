@@ -879,6 +879,33 @@ __device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, 
     return o;
 }
 
+// SPEC §5 env order from the key totals: runs of the keys 1..6 in key order; after every non-empty run, envs of
+// key 0 (no option) pad the position up to the next multiple of the workgroup size while any are left — a
+// workgroup then never holds two options' runs (those paid a third pass: +4 % on the launch) — and the rest of
+// key 0 comes last. All lanes compute the same few integers.
+struct OrderLayout {
+    int base[7], pad_lo[7], pad_n[7], pad_pos[7], tail_lo, tail_pos;
+};
+__device__ __forceinline__ void order_layout(const int tot[7], OrderLayout &L) {
+    int P = 0, used = 0;
+    L.base[0] = 0; L.pad_lo[0] = 0; L.pad_n[0] = 0; L.pad_pos[0] = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) {
+        L.base[k] = P; P += tot[k];
+        const int need = tot[k] > 0 ? (BLOCK_ENVS - P % BLOCK_ENVS) % BLOCK_ENVS : 0;
+        const int pad = min(need, tot[0] - used);
+        L.pad_lo[k] = used; L.pad_n[k] = pad; L.pad_pos[k] = P; used += pad; P += pad;
+    }
+    L.tail_lo = used; L.tail_pos = P;
+}
+__device__ __forceinline__ int order_pos0(const OrderLayout &L, int r) {       // position of the r-th key-0 env
+    int pos = L.tail_pos + (r - L.tail_lo);
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+        if (r >= L.pad_lo[k] && r < L.pad_lo[k] + L.pad_n[k]) pos = L.pad_pos[k] + (r - L.pad_lo[k]);
+    return pos;
+}
+
 // One wave per row of 256 envs (no LDS, no barriers), two dependent memory round trips in all:
 //   commit: gather each env's result line from its position in the current order (one 64-byte read) and write
 //           the caller's SoA arrays (state, outputs, qcache) with full-line stores;
@@ -915,15 +942,17 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
         ra[j] = r[0]; rb[j] = r[1]; rq[j] = r[2]; q4[j] = r[3].x;
     }
     int off[7];
+    OrderLayout L;
     if (R.sort) {
-        int before = 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {                   // integer sums: any order
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
-            off[k] = before + pre[k];
-            before += tot[k];
         }
+        order_layout(tot, L);
+        off[0] = pre[0];                                // key 0: rank among the key-0 envs (placed by order_pos0)
+#pragma unroll
+        for (int k = 1; k < 7; ++k) off[k] = L.base[k] + pre[k];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -949,6 +978,7 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
                 if (key == k) pos = off[k] + __popcll(m & ((1ull << lane) - 1ull));
                 off[k] += __popcll(m);
             }
+            if (key == 0) pos = order_pos0(L, pos);
             if (pos >= 0) { R.perm[pos] = e; R.invperm[e] = pos; }
         }
     }
@@ -1107,11 +1137,12 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
         s_pre[tid] = s_part[0][8 + tid] + s_part[1][8 + tid] + s_part[2][8 + tid] + s_part[3][8 + tid];
     }
     __syncthreads();
-    if (tid < 7) {
-        int before = 0;
-        for (int kk = 0; kk < tid; ++kk) before += s_tot[kk];
-        s_off[tid] = before + s_pre[tid];
-    }
+    int tt[7];
+#pragma unroll
+    for (int kk = 0; kk < 7; ++kk) tt[kk] = s_tot[kk];
+    OrderLayout L;
+    order_layout(tt, L);
+    if (tid < 7) s_off[tid] = (tid == 0 ? 0 : L.base[tid]) + s_pre[tid];      // key 0: rank, placed by order_pos0
     const int e = b * 256 + tid;
     int o = e < n ? option_id[e] : -1;
     if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;
@@ -1126,6 +1157,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
     if (o >= 0) {
         int pos = s_off[o] + rank;
         for (int w = 0; w < wave; ++w) pos += s_c[w][o];
+        if (o == 0) pos = order_pos0(L, pos);
         perm[pos] = e;
         invperm[e] = pos;
     }
