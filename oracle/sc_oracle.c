@@ -377,39 +377,52 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
      * and blocks are 256 consecutive positions of that order. Every per-env array stays indexed by env. */
     int *perm = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
     {
-        /* key of an env: its option id, ids outside [0, n_vf) -> n_vf (never produced by the step). Runs of the
-         * keys 1..6 follow one another in key order, envs in env order inside a run; after every non-empty run,
-         * envs of key 0 (running no option), in env order, pad the position up to the next multiple of the block
-         * size while any are left, so that a block never holds two options' runs; what remains of key 0 comes last. */
+        /* SPEC §5 env order. Key of an env: its option id, ids outside [0, n_vf) -> n_vf (never produced by the
+         * step). Runs of the keys 1..6 in key order, envs in env order inside a run; envs of key 0 (running no
+         * option), in env order, are the filler. */
         int tot[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int e = 0; e < N; ++e) {
             int o = option_id[e];
             if (o < 0 || o >= n_vf) o = n_vf;
             tot[o]++;
         }
-        int base[7], pad_lo[7], pad_n[7], pad_pos[7];
-        int Pp = 0, used = 0;
-        for (int k = 1; k < 7; ++k) {
-            base[k] = Pp; Pp += tot[k];
-            int need = tot[k] > 0 ? (g_block_envs - Pp % g_block_envs) % g_block_envs : 0;
-            int pad = need < tot[0] - used ? need : tot[0] - used;
-            pad_lo[k] = used; pad_n[k] = pad; pad_pos[k] = Pp; used += pad; Pp += pad;
-        }
-        const int tail_lo = used, tail_pos = Pp;
-        int rank[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int e = 0; e < N; ++e) {
-            int o = option_id[e];
-            if (o < 0 || o >= n_vf) o = n_vf;
-            const int r = rank[o]++;
-            int pos;
-            if (o > 0) pos = base[o] + r;
-            else {
-                pos = tail_pos + (r - tail_lo);
-                for (int k = 1; k < 7; ++k)
-                    if (r >= pad_lo[k] && r < pad_lo[k] + pad_n[k]) pos = pad_pos[k] + (r - pad_lo[k]);
+        /* lists of envs per key, env order */
+        int *lst[7], fillpos = 0;
+        for (int k = 0; k < 7; ++k) lst[k] = (int *)malloc(sizeof(int) * (size_t)(tot[k] > 0 ? tot[k] : 1));
+        {
+            int cnt7[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int e = 0; e < N; ++e) {
+                int o = option_id[e];
+                if (o < 0 || o >= n_vf) o = n_vf;
+                lst[o][cnt7[o]++] = e;
             }
-            perm[pos] = e;
         }
+        int S = 0, Rn = 0;
+        for (int k = 1; k < 7; ++k) { S += tot[k]; Rn += tot[k] > 0; }
+        const int B = g_block_envs, Bf = N / B;
+        int c = B;
+        if (Bf > Rn && S > 0) { c = (S + (Bf - Rn) - 1) / (Bf - Rn); if (c > B) c = B; }
+        int U = 0;
+        for (int k = 1; k < 7; ++k) U += (tot[k] + c - 1) / c;
+        int pos = 0;
+        if ((long)U * B <= N) {
+            /* chunked layout: every block takes at most c envs of one run, key-0 envs fill it up */
+            for (int k = 1; k < 7; ++k)
+                for (int r = 0; r < tot[k]; r += c) {
+                    const int m = tot[k] - r < c ? tot[k] - r : c;
+                    for (int i = 0; i < m; ++i) perm[pos++] = lst[k][r + i];
+                    for (int i = m; i < B; ++i) perm[pos++] = lst[0][fillpos++];
+                }
+        } else {
+            /* padded layout: runs back to back, each padded to the next block boundary while key-0 envs are left */
+            for (int k = 1; k < 7; ++k) {
+                for (int r = 0; r < tot[k]; ++r) perm[pos++] = lst[k][r];
+                if (tot[k] > 0)
+                    while (pos % B != 0 && fillpos < tot[0]) perm[pos++] = lst[0][fillpos++];
+            }
+        }
+        while (fillpos < tot[0]) perm[pos++] = lst[0][fillpos++];
+        for (int k = 0; k < 7; ++k) free(lst[k]);
     }
     float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * n_vf * NACT * NF);
     int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1) * n_vf, sizeof(int));

@@ -879,30 +879,90 @@ __device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, 
     return o;
 }
 
-// SPEC §5 env order from the key totals: runs of the keys 1..6 in key order; after every non-empty run, envs of
-// key 0 (no option) pad the position up to the next multiple of the workgroup size while any are left — a
-// workgroup then never holds two options' runs (those paid a third pass: +4 % on the launch) — and the rest of
-// key 0 comes last. All lanes compute the same few integers.
+// SPEC §5 env order from the key totals (all lanes compute the same few integers). Runs of the keys 1..6 follow one
+// another in key order; envs of key 0 (running no option) are the filler:
+//  * chunked layout (the normal case): every workgroup gets at most c envs of one option's run at its start and
+//    key-0 envs behind them, with c = ceil(S / (full workgroups - non-empty runs)) — so the option work is spread
+//    evenly over ALL workgroups instead of leaving the key-0 workgroups idle after their root pass (one workgroup
+//    per CU: the launch lasts as long as its slowest), and no workgroup ever holds two options' runs (a third
+//    pass). What is left of key 0 comes last.
+//  * padded layout (when the option runs alone need more workgroups than there are full ones): runs back to back,
+//    each padded with key-0 envs to the next workgroup boundary while any are left.
+// floor(r / d) for r < 2^24, d <= 2^30, with m = ceil(2^32 / d) (m wraps to 0 for d = 1)
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xFFFFFFFFu / d + 1u; }
+__device__ __forceinline__ int div_by(int r, int d, uint32_t m) { return d == 1 ? r : (int)__umulhi((uint32_t)r, m); }
 struct OrderLayout {
-    int base[7], pad_lo[7], pad_n[7], pad_pos[7], tail_lo, tail_pos;
+    int chunked, c, g, U, Ftot;
+    uint32_t mc, mg;               // ceil(2^32 / c), ceil(2^32 / g): exact division of ranks (< 2^24) by mul-high
+    int start[7];                  // position of run k's first env
+    int cnt[7], n[7], F[7];        // chunked: workgroups of run k, its size, key-0 fill slots before it
+    int pad_lo[7], pad_n[7], pad_pos[7], tail_lo, tail_pos;     // padded layout
 };
-__device__ __forceinline__ void order_layout(const int tot[7], OrderLayout &L) {
-    int P = 0, used = 0;
-    L.base[0] = 0; L.pad_lo[0] = 0; L.pad_n[0] = 0; L.pad_pos[0] = 0;
+__device__ __forceinline__ void order_layout(const int tot[7], int n_envs, OrderLayout &L) {
+    int S = 0, Rn = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) { S += tot[k]; Rn += tot[k] > 0 ? 1 : 0; L.n[k] = tot[k]; }
+    L.n[0] = tot[0];
+    const int Bf = n_envs / BLOCK_ENVS;
+    int c = BLOCK_ENVS;
+    if (Bf > Rn && S > 0) c = min(BLOCK_ENVS, (S + (Bf - Rn) - 1) / (Bf - Rn));
+    int U = 0, F = 0;
+    L.start[0] = 0; L.cnt[0] = 0; L.F[0] = 0;
+    L.mc = div_magic((uint32_t)c);
+    L.mg = div_magic((uint32_t)max(BLOCK_ENVS - c, 1));
 #pragma unroll
     for (int k = 1; k < 7; ++k) {
-        L.base[k] = P; P += tot[k];
-        const int need = tot[k] > 0 ? (BLOCK_ENVS - P % BLOCK_ENVS) % BLOCK_ENVS : 0;
-        const int pad = min(need, tot[0] - used);
-        L.pad_lo[k] = used; L.pad_n[k] = pad; L.pad_pos[k] = P; used += pad; P += pad;
+        L.cnt[k] = div_by(tot[k] + c - 1, c, L.mc);
+        L.start[k] = U * BLOCK_ENVS; L.F[k] = F;
+        U += L.cnt[k]; F += L.cnt[k] * BLOCK_ENVS - tot[k];
     }
-    L.tail_lo = used; L.tail_pos = P;
+    L.c = c; L.g = BLOCK_ENVS - c; L.U = U; L.Ftot = F;
+    L.chunked = (U * BLOCK_ENVS <= n_envs) ? 1 : 0;
+    if (!L.chunked) {
+        int P = 0, used = 0;
+        L.c = 1 << 30;                                  // one "chunk" per run: pos = start + rank
+        L.mc = div_magic(1u << 30);
+        L.pad_lo[0] = 0; L.pad_n[0] = 0; L.pad_pos[0] = 0;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) {
+            L.start[k] = P; P += tot[k];
+            const int need = tot[k] > 0 ? (BLOCK_ENVS - P % BLOCK_ENVS) % BLOCK_ENVS : 0;
+            const int pad = min(need, tot[0] - used);
+            L.pad_lo[k] = used; L.pad_n[k] = pad; L.pad_pos[k] = P; used += pad; P += pad;
+        }
+        L.tail_lo = used; L.tail_pos = P;
+    }
+}
+// position of the r-th env of run k (k >= 1; `start` = L.start[k] selected by the caller)
+__device__ __forceinline__ int order_posk(const OrderLayout &L, int start, int r) {
+    const int t = div_by(r, L.c, L.mc);
+    return start + BLOCK_ENVS * t + (r - t * L.c);
 }
 __device__ __forceinline__ int order_pos0(const OrderLayout &L, int r) {       // position of the r-th key-0 env
-    int pos = L.tail_pos + (r - L.tail_lo);
+    if (!L.chunked) {
+        int pos = L.tail_pos + (r - L.tail_lo);
 #pragma unroll
-    for (int k = 1; k < 7; ++k)
-        if (r >= L.pad_lo[k] && r < L.pad_lo[k] + L.pad_n[k]) pos = L.pad_pos[k] + (r - L.pad_lo[k]);
+        for (int k = 1; k < 7; ++k)
+            if (r >= L.pad_lo[k] && r < L.pad_lo[k] + L.pad_n[k]) pos = L.pad_pos[k] + (r - L.pad_lo[k]);
+        return pos;
+    }
+    int pos = L.U * BLOCK_ENVS + (r - L.Ftot);          // behind all runs
+    int st = 0, cn = 0, nk = 0, f0 = 0;
+    bool in_run = false;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) {
+        const int fills = L.cnt[k] * BLOCK_ENVS - L.n[k];
+        if (r >= L.F[k] && r < L.F[k] + fills) { in_run = true; st = L.start[k]; cn = L.cnt[k]; nk = L.n[k]; f0 = L.F[k]; }
+    }
+    if (in_run) {
+        const int rp = r - f0, nfull = cn - 1;
+        if (L.g > 0 && rp < nfull * L.g) {
+            const int t = div_by(rp, L.g, L.mg);
+            pos = st + BLOCK_ENVS * t + L.c + (rp - t * L.g);
+        } else {
+            pos = st + BLOCK_ENVS * nfull + (nk - nfull * L.c) + (rp - nfull * L.g);
+        }
+    }
     return pos;
 }
 
@@ -949,10 +1009,9 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
         }
-        order_layout(tot, L);
-        off[0] = pre[0];                                // key 0: rank among the key-0 envs (placed by order_pos0)
+        order_layout(tot, R.n, L);
 #pragma unroll
-        for (int k = 1; k < 7; ++k) off[k] = L.base[k] + pre[k];
+        for (int k = 0; k < 7; ++k) off[k] = pre[k];    // rank of the row's first key-k env within its run
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -971,15 +1030,17 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
             }
         }
         if (R.sort) {
-            int pos = -1;
+            int rk = -1, st = 0;
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 const uint64_t m = __ballot(key == k);
-                if (key == k) pos = off[k] + __popcll(m & ((1ull << lane) - 1ull));
+                if (key == k) { rk = off[k] + __popcll(m & ((1ull << lane) - 1ull)); st = L.start[k]; }
                 off[k] += __popcll(m);
             }
-            if (key == 0) pos = order_pos0(L, pos);
-            if (pos >= 0) { R.perm[pos] = e; R.invperm[e] = pos; }
+            if (rk >= 0) {
+                const int pos = key == 0 ? order_pos0(L, rk) : order_posk(L, st, rk);
+                R.perm[pos] = e; R.invperm[e] = pos;
+            }
         }
     }
     if (R.sort && lane < 8) R.hist_zero[row * 8 + lane] = 0;
@@ -1141,8 +1202,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
 #pragma unroll
     for (int kk = 0; kk < 7; ++kk) tt[kk] = s_tot[kk];
     OrderLayout L;
-    order_layout(tt, L);
-    if (tid < 7) s_off[tid] = (tid == 0 ? 0 : L.base[tid]) + s_pre[tid];      // key 0: rank, placed by order_pos0
+    order_layout(tt, n, L);
+    if (tid < 7) s_off[tid] = s_pre[tid];               // rank of the row's first key-k env within its run
     const int e = b * 256 + tid;
     int o = e < n ? option_id[e] : -1;
     if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;
@@ -1155,9 +1216,12 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
     }
     __syncthreads();
     if (o >= 0) {
-        int pos = s_off[o] + rank;
-        for (int w = 0; w < wave; ++w) pos += s_c[w][o];
-        if (o == 0) pos = order_pos0(L, pos);
+        int rk = s_off[o] + rank;
+        for (int w = 0; w < wave; ++w) rk += s_c[w][o];
+        int st = 0;
+#pragma unroll
+        for (int k = 1; k < 7; ++k) if (o == k) st = L.start[k];
+        const int pos = o == 0 ? order_pos0(L, rk) : order_posk(L, st, rk);
         perm[pos] = e;
         invperm[e] = pos;
     }
