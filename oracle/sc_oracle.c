@@ -16,7 +16,7 @@
 
 #define NACT SCO_NACT
 /* SPEC §5 geometry: envs per block and wavefronts per block (256/8 by default; 128/4 is the other build) */
-static int g_block_envs = SCO_BLOCK_ENVS, g_waves = SCO_WAVES;
+static int g_block_envs = SCO_BLOCK_ENVS_DEFAULT, g_waves = SCO_WAVES_DEFAULT;
 void sco_set_geometry(int block_envs, int waves) { g_block_envs = block_envs; g_waves = waves; }
 #define NF SCO_NF
 #define NLANE 64

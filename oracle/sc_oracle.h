@@ -18,8 +18,10 @@ extern "C" {
 
 #define SCO_NACT 5
 #define SCO_NF 1296
-#define SCO_BLOCK_ENVS 256
+#define SCO_BLOCK_ENVS 256          /* largest block geometry supported (array bound) */
 #define SCO_WAVES 8
+#define SCO_BLOCK_ENVS_DEFAULT 128  /* SPEC §5 */
+#define SCO_WAVES_DEFAULT 4
 #define SCO_CLF_STRIDE 8
 
 typedef struct {

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsc_oracle.so")
-NACT, NF, CLF_STRIDE, BLOCK_ENVS, WAVES = 5, 1296, 8, 256, 8
+NACT, NF, CLF_STRIDE, BLOCK_ENVS, WAVES = 5, 1296, 8, 128, 4
 
 
 class Params(C.Structure):

@@ -12,9 +12,9 @@ constexpr int NACT = 5;
 constexpr int NF = 1296;
 constexpr int NSLOT = 21;          // feature slots per lane (SPEC §3.1)
 #ifndef SCG_BLOCK_ENVS
-#define SCG_BLOCK_ENVS 256
+#define SCG_BLOCK_ENVS 128
 #endif
-constexpr int BLOCK_ENVS = SCG_BLOCK_ENVS;    // SPEC §5 geometry: envs per workgroup (256 or 128)
+constexpr int BLOCK_ENVS = SCG_BLOCK_ENVS;    // SPEC §5 geometry: envs per workgroup (128; `make b256` builds the 256-env variant)
 constexpr int WAVES = BLOCK_ENVS / 32;        // 32 envs per wavefront in phase P
 constexpr int LIST_WAVES = BLOCK_ENVS / 64;   // waves that ballot the workgroup's env flags
 constexpr int THREADS = WAVES * 64;

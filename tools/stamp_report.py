@@ -19,7 +19,7 @@ for _ in range(10): agent.step_batch()
 torch.cuda.synchronize()
 lib, ctx = agent.ctx.lib, agent.ctx._ctx
 lib.scg_diag_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
-nblk = n // 256
+nblk = n // lib.scg_block_envs()
 lib.scg_diag_stamps(ctx, None, 1)
 for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
@@ -34,4 +34,4 @@ for nme, v in zip(names, mean): print(f"  {nme:22s} {v:10.0f}  {100*v/tot:5.1f} 
 per_block = out.astype(np.float64).sum(1) / args.steps
 print(f"per-block wave-0 total ticks per launch: min {per_block.min():.0f}  mean {per_block.mean():.0f}  max {per_block.max():.0f}"
       f"  (mean/max = {per_block.mean()/per_block.max():.2f}: one workgroup per CU, the launch lasts as long as its slowest)")
-print("  by block index (sorted env order, 16 blocks per bin):", np.round(per_block.reshape(-1, 16).mean(1)).astype(int).tolist())
+print("  by block index (env order, 16 bins):", np.round(per_block.reshape(16, -1).mean(1)).astype(int).tolist())
