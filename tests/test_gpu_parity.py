@@ -220,6 +220,50 @@ def test_packed_gradient_operand_matches_the_split_pair():
     assert n_k[1:].sum() > 0
 
 
+@pytest.mark.parametrize("n,dist", [
+    (127, "uniform"), (129, "uniform"), (1000, "all3"), (1000, "none"), (1000, "heavy"), (4100, "uniform"),
+    (4100, "one_each"), (4100, "heavy"), (2048, "no_root"),
+])
+def test_env_order_layouts_bit_exact(n, dist):
+    """SPEC §5's env order in all its regimes — chunked and padded layouts, ragged last block, empty runs, no
+    filler envs at all — through both sort paths (stand-alone kernels on step 0, the reduce launch's row
+    workgroups afterwards), bit-exact against the oracle's procedural construction."""
+    import torch
+    nopt, mask = 5, 0b111110
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=nopt, seed=6, enabled_mask=mask)
+    clf = chain_classifiers(m, nopt)
+    rng = np.random.default_rng(n + len(dist))
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 23, vmax=1.0)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    if dist == "uniform":
+        opt = rng.integers(0, nopt + 1, n)
+    elif dist == "all3":
+        opt = np.full(n, 3)
+    elif dist == "none":
+        opt = np.zeros(n, int)
+    elif dist == "heavy":
+        opt = np.where(rng.random(n) < 0.95, rng.integers(1, nopt + 1, n), 0)
+    elif dist == "one_each":
+        opt = np.zeros(n, int); opt[[5, 700, 1300, 2500, 4000]] = [1, 2, 3, 4, 5]
+    else:                                                # no_root: nobody can serve as filler
+        opt = rng.integers(1, nopt + 1, n)
+    st_o["option_id"][:] = opt
+    st_o["opt_steps"][:] = rng.integers(0, 5, n) * (opt > 0)
+    W_o = random_weights(nopt + 1, 16, std=0.05)
+    st_d = state_to_device(st_o, ctx)
+    W_d, clf_d = dev(W_o.copy()), dev(clf)
+    G_d, n_d = ctx.grad_buffers()
+    for t in range(3):
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        orc.apply(W_o, G, n_k)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), mask, t)
+        assert_state_equal(st_d, st_o, msg=f"t={t}")
+        assert np.array_equal(n_d.cpu().numpy(), n_k), t
+        assert np.array_equal(G_d.cpu().numpy(), G), t
+        assert np.array_equal(W_d.cpu().numpy(), W_o), t
+
+
 def test_host_checks_fail_before_any_launch():
     from skill_chaining_with_graphs_amd import ScgError
     ctx, orc, m = make_pair("pinball_simple", 64)
