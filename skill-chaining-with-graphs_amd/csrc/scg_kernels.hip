@@ -551,7 +551,10 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         } else {
             // 128-env workgroups (two per CU): no LDS room for the 26 KB staging area — every wave fetches its
             // 105 weights per lane through the buffer descriptor (L2-resident)
+            // (waves that get no quad of the eval list skip the fetch: evaluation-only passes — envs ENTERING an option
+            // nobody here runs, 1.6 per workgroup on the bench workload — have one or two quads)
             const uint32_t kb = (MODE == MODE_QVAL) ? 0u : (uint32_t)k * (NACT * NF * 4);
+            if (wave < ((n_ev + 3) >> 2)) {
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
 #pragma unroll
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         w_rsrc, (t < 2 || v20) ? w_vt : 0u, kb + (uint32_t)(a * NF + 576 * t) * 4u, 0));
                     SCG_R_SET(a, 18 + t, (t < 2 || v20) ? v : 0.0f);
                 }
+            }
             }
         }
         SCG_STAMP(k == 0 ? 2 : 9);    // W staging
