@@ -21,11 +21,14 @@ for k in range(1,7):
         ch=lst[k][r:r+c]; perm+=list(ch); m=B-len(ch); perm+=list(lst[0][fill:fill+m]); fill+=m
 perm+=list(lst[0][fill:]); perm=np.array(perm)
 assert len(perm)==n and len(set(perm))==n
-nb=n//B; upd_passes=0; eval_only=0; hist=np.zeros(8,int)
+nb=n//B; upd_passes=0; eval_only=0; hist=np.zeros(8,int); items=[]
 for b in range(nb):
     e=perm[b*B:(b+1)*B]
     up=set(o[e].tolist())|{0}
     ev=set(on[e].tolist())
     eo=len(ev-up); eval_only+=eo; upd_passes+=len(up); hist[eo]+=1
+    for v in ev-up: items.append(int((on[e]==v).sum()))
 print("blocks",nb,"chunk c",c,"update passes/block",upd_passes/nb,"eval-only passes/block",eval_only/nb,"hist of eval-only per block",hist.tolist())
 print("option counts",tot.tolist())
+
+items=np.array(items); print("items per evaluation-only pass: mean %.1f, median %d, p90 %d, max %d; quads mean %.2f" % (items.mean(), np.median(items), np.percentile(items,90), items.max(), np.ceil(items/4).mean()))
