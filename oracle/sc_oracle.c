@@ -15,12 +15,9 @@
 #endif
 
 #define NACT SCO_NACT
-/* SPEC §5 geometry: envs per block and wavefronts per block (256/8 by default; 128/4 is the other build) */
-static int g_block_envs = SCO_BLOCK_ENVS_DEFAULT, g_waves = SCO_WAVES_DEFAULT;
-void sco_set_geometry(int block_envs, int waves) { g_block_envs = block_envs; g_waves = waves; }
+/* SPEC §5 geometry: envs per block (a block's update items share one accumulation chain per weight) */
+static const int g_block_envs = SCO_BLOCK_ENVS;
 #define NF SCO_NF
-#define NLANE 64
-#define NSLOT 21
 
 /* ------------------------------------------------------------------ SPEC §2: Philox4x32-10 */
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -94,41 +91,29 @@ static void state_features(float x, float y, float vx, float vy, float *phi) {
             phi[c12 * 36 + c34] = fmaf(-AB[c12].im, CD[c34].im, AB[c12].re * CD[c34].re);
 }
 
-/* ------------------------------------------------------------------ SPEC §3.1: canonical wave order */
-int sco_feature_index(int lane, int slot) {
-    if (lane < 0 || lane >= NLANE || slot < 0 || slot >= NSLOT) return -1;
-    if (slot < 16) return (8 * (slot >> 2) + 4 * (lane >> 5) + (slot & 3)) * 36 + (lane & 31);
-    if (slot < 18) return (2 * slot + (lane >> 5)) * 36 + (lane & 31);
-    int idx = 64 * (slot - 18) + lane;
-    if (idx >= 144) return -1;
-    return (idx >> 2) * 36 + 32 + (idx & 3);
-}
+/* ------------------------------------------------------------------ SPEC §3.1: Q_k(sigma, a) */
+typedef struct { cplx AB[36], CD[36]; } st_tab;
 
-static int g_order[NLANE][NSLOT];
-static int g_order_ready = 0;
-static void init_order(void) {
-    if (g_order_ready) return;
-    for (int l = 0; l < NLANE; ++l)
-        for (int j = 0; j < NSLOT; ++j) g_order[l][j] = sco_feature_index(l, j);
-    g_order_ready = 1;
-}
-
-static float wave_dot(const float *w, const float *phi) {
-    float p[NLANE];
-    for (int l = 0; l < NLANE; ++l) {
-        float acc = 0.0f;
-        for (int j = 0; j < NSLOT; ++j) {
-            int f = g_order[l][j];
-            if (f >= 0) acc = fmaf(w[f], phi[f], acc);
-        }
-        p[l] = acc;
+/* Wa = W_k[a] as [36][36] (c12 major). Two contractions: T[c12][part] over c34 in the order c34 = 9 g + kb
+ * (kb = 0..8 outer, g = 0..3 inner), then four partial chains over c12 (one per row group) and a fixed tree. */
+static float q_value(const float *Wa, int a, const st_tab *tb) {
+    float q[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+    for (int c12 = 0; c12 < 36; ++c12) {
+        float tre = 0.0f, tim = 0.0f;
+        for (int kb = 0; kb < 9; ++kb)
+            for (int g = 0; g < 4; ++g) {
+                const int c34 = 9 * g + kb;
+                const float w = Wa[c12 * 36 + c34];
+                tre = fmaf(w, tb->CD[c34].re, tre);
+                tim = fmaf(w, tb->CD[c34].im, tim);
+            }
+        const int grp = ((36 * a + c12) % 16) / 4;
+        q[grp][0] = fmaf(tre, tb->AB[c12].re, q[grp][0]);
+        q[grp][1] = fmaf(tim, -tb->AB[c12].im, q[grp][1]);
     }
-    for (int m = 1; m < NLANE; m <<= 1) {
-        float q[NLANE];
-        for (int l = 0; l < NLANE; ++l) q[l] = p[l] + p[l ^ m];
-        memcpy(p, q, sizeof p);
-    }
-    return p[0];
+    float u[4];
+    for (int g = 0; g < 4; ++g) u[g] = q[g][0] + q[g][1];
+    return (u[0] + u[1]) + (u[2] + u[3]);
 }
 
 /* ------------------------------------------------------------------ SPEC §1.3: physics */
@@ -207,13 +192,11 @@ void sco_features(int n, const float *x, const float *y, const float *vx, const 
 
 void sco_q_values(int n, const float *x, const float *y, const float *vx, const float *vy,
                   const float *Wk, float *q) {
-    init_order();
-    float *phi = (float *)malloc(sizeof(float) * NF);
     for (int e = 0; e < n; ++e) {
-        state_features(x[e], y[e], vx[e], vy[e], phi);
-        for (int a = 0; a < NACT; ++a) q[(size_t)a * n + e] = wave_dot(Wk + a * NF, phi);
+        st_tab tb;
+        state_tables(x[e], y[e], vx[e], vy[e], tb.AB, tb.CD);
+        for (int a = 0; a < NACT; ++a) q[(size_t)a * n + e] = q_value(Wk + a * NF, a, &tb);
     }
-    free(phi);
 }
 
 /* ------------------------------------------------------------------ SPEC §4.1: classifier */
@@ -242,9 +225,8 @@ typedef struct {
     /* per VF flags for this env, filled by the caller */
 } env_rec;
 
-/* One (block, VF) pass. items: indices into the block (0..nb-1) in env order with flags.
- * phi_s / phi_n: [nb][1296] feature rows of s and s_next (computed lazily by the caller).
- * Adds the block partial P_b,k into Pout[5][1296] (overwrites). */
+/* One (block, VF) pass. items: block-local env indices in block order with flags; tab_s / tab_n: the AB / CD
+ * tables of s and s_next of every env of the block. Writes the block partial P_b,k into Pout[5][1296]. */
 typedef struct {
     int env;      /* block-local env index */
     int upd, tgt, cache;
@@ -252,18 +234,15 @@ typedef struct {
 } td_item;
 
 static void block_vf_pass(const float *Wk, int n_items, const td_item *items, const env_rec *rec,
-                          const float *phi_s, const float *phi_n, float *qcache, int qstride,
+                          const st_tab *tab_s, const st_tab *tab_n, float *qcache, int qstride,
                           const int *env_of, float *Pout, int *n_upd) {
-    /* acc[wave][a][f]. Evaluations first (order-free: each item's Q values depend on nothing else). */
-    float *acc = (float *)calloc((size_t)g_waves * NACT * NF, sizeof(float));
+    /* evaluations (order-free: each item's Q values depend on nothing else) */
     float *maxq = (float *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(float));
-    int cnt = 0;
     for (int i = 0; i < n_items; ++i) {
         const td_item *it = &items[i];
         if (it->tgt || it->cache) {
             float qn[NACT];
-            const float *pn = phi_n + (size_t)it->env * NF;
-            for (int a = 0; a < NACT; ++a) qn[a] = wave_dot(Wk + a * NF, pn);
+            for (int a = 0; a < NACT; ++a) qn[a] = q_value(Wk + a * NF, a, &tab_n[it->env]);
             if (it->cache)
                 for (int a = 0; a < NACT; ++a) qcache[(size_t)a * qstride + env_of[it->env]] = qn[a];
             float m = qn[0];
@@ -271,32 +250,41 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
             maxq[i] = m;
         }
     }
-    /* SPEC §5: update items sorted by (action, env); quads of 4 within an action run; quad q -> wave q mod 8 */
-    int q = 0;
+    /* SPEC §5 accumulation: per action, the run of update items in block order, in groups of four (the last
+     * group padded with null items whose operands are +0); inside a group first the real parts of the four
+     * items, then the imaginary parts: G = fma(P, C, G) with P = delta * ABsel, C = CD. */
+    memset(Pout, 0, sizeof(float) * NACT * NF);
+    int cnt = 0;
+    int *run = (int *)malloc(sizeof(int) * (size_t)(n_items > 0 ? n_items : 1));
+    float *dl = (float *)malloc(sizeof(float) * (size_t)(n_items > 0 ? n_items : 1));
     for (int act = 0; act < NACT; ++act) {
-        int in_run = 0;
+        int m = 0;
         for (int i = 0; i < n_items; ++i) {
             const td_item *it = &items[i];
-            const env_rec *r = &rec[it->env];
-            if (!it->upd || r->a != act) continue;
-            int w = (q + in_run / 4) % g_waves;
-            const float *ps = phi_s + (size_t)it->env * NF;
-            float qsa = wave_dot(Wk + r->a * NF, ps);
+            if (!it->upd || rec[it->env].a != act) continue;
+            float qsa = q_value(Wk + act * NF, act, &tab_s[it->env]);
             float target = it->tgt ? fmaf(it->cont, maxq[i], it->r) : it->r;
-            float delta = target - qsa;
-            float *dst = acc + ((size_t)w * NACT + r->a) * NF;
-            for (int f = 0; f < NF; ++f) dst[f] = fmaf(delta, ps[f], dst[f]);
-            ++cnt; ++in_run;
+            dl[m] = target - qsa;
+            run[m++] = it->env;
         }
-        q += (in_run + 3) / 4;
+        cnt += m;
+        float *Ga = Pout + (size_t)act * NF;
+        for (int g0 = 0; g0 < m; g0 += 4)
+            for (int part = 0; part < 2; ++part)
+                for (int j = 0; j < 4; ++j) {
+                    const int null = g0 + j >= m;
+                    const st_tab *tb = null ? NULL : &tab_s[run[g0 + j]];
+                    const float d = null ? 0.0f : dl[g0 + j];
+                    float cc[36];
+                    for (int c34 = 0; c34 < 36; ++c34) cc[c34] = null ? 0.0f : (part ? tb->CD[c34].im : tb->CD[c34].re);
+                    for (int c12 = 0; c12 < 36; ++c12) {
+                        const float pp = null ? 0.0f : (part ? d * (-tb->AB[c12].im) : d * tb->AB[c12].re);
+                        float *row = Ga + c12 * 36;
+                        for (int c34 = 0; c34 < 36; ++c34) row[c34] = fmaf(pp, cc[c34], row[c34]);
+                    }
+                }
     }
-    free(maxq);
-    for (size_t i = 0; i < (size_t)NACT * NF; ++i) {
-        float s = acc[i];
-        for (int w = 1; w < g_waves; ++w) s = s + acc[(size_t)w * NACT * NF + i];
-        Pout[i] = s;
-    }
-    free(acc);
+    free(run); free(dl); free(maxq);
     *n_upd = cnt;
 }
 
@@ -318,7 +306,6 @@ static float seg_sum(const float *P, size_t stride, size_t idx, int nblk) {
 
 int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint8_t *action,
                       const float *r, const float *cont, const float *sn4[4], const float *Wk, float *G) {
-    init_order();
     int nblk = (n + g_block_envs - 1) / g_block_envs;
     float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * NACT * NF);
     int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1), sizeof(int));
@@ -330,8 +317,8 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
         int nb = n - e0 < g_block_envs ? n - e0 : g_block_envs;
         env_rec *rec = (env_rec *)malloc(sizeof(env_rec) * nb);
         td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
-        float *phi_s = (float *)malloc(sizeof(float) * (size_t)nb * NF);
-        float *phi_n = (float *)malloc(sizeof(float) * (size_t)nb * NF);
+        st_tab *tab_s = (st_tab *)malloc(sizeof(st_tab) * nb);
+        st_tab *tab_n = (st_tab *)malloc(sizeof(st_tab) * nb);
         float dummy_q[NACT];
         for (int i = 0; i < nb; ++i) {
             int e = e0 + i;
@@ -339,12 +326,12 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
             rec[i].a = action[e];
             items[i].env = i; items[i].upd = 1; items[i].tgt = cont[e] > 0.0f; items[i].cache = 0;
             items[i].r = r[e]; items[i].cont = cont[e];
-            state_features(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], phi_s + (size_t)i * NF);
+            state_tables(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], tab_s[i].AB, tab_s[i].CD);
             if (items[i].tgt)
-                state_features(rec[i].sn[0], rec[i].sn[1], rec[i].sn[2], rec[i].sn[3], phi_n + (size_t)i * NF);
+                state_tables(rec[i].sn[0], rec[i].sn[1], rec[i].sn[2], rec[i].sn[3], tab_n[i].AB, tab_n[i].CD);
         }
-        block_vf_pass(Wk, nb, items, rec, phi_s, phi_n, dummy_q, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b]);
-        free(rec); free(items); free(phi_s); free(phi_n);
+        block_vf_pass(Wk, nb, items, rec, tab_s, tab_n, dummy_q, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b]);
+        free(rec); free(items); free(tab_s); free(tab_n);
     }
     int total = 0;
     for (size_t i = 0; i < (size_t)NACT * NF; ++i) G[i] = seg_sum(P, (size_t)NACT * NF, i, nblk);
@@ -369,12 +356,11 @@ void sco_apply(const sco_params *p, int n_vf, float *W, const float *G, const in
 void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int32_t *option_id,
               int32_t *opt_steps, int32_t *ep_steps, float *qcache, uint8_t *action, float *reward,
               uint8_t *done, const float *W, const float *clf, uint64_t t, float *G, int32_t *n_k) {
-    init_order();
     const int N = p->n_envs;
     const int n_vf = p->n_options + 1;
     const int nblk = (N + g_block_envs - 1) / g_block_envs;
     /* SPEC §5: envs are taken in the order of (option_id at entry, env index) — a stable counting sort —
-     * and blocks are 256 consecutive positions of that order. Every per-env array stays indexed by env. */
+     * and blocks are 128 consecutive positions of that order. Every per-env array stays indexed by env. */
     int *perm = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
     {
         /* SPEC §5 env order. Key of an env: its option id, ids outside [0, n_vf) -> n_vf (never produced by the
@@ -435,8 +421,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         env_rec rec[SCO_BLOCK_ENVS];
         int o_t[SCO_BLOCK_ENVS], o_n[SCO_BLOCK_ENVS];
         float r0[SCO_BLOCK_ENVS], c0[SCO_BLOCK_ENVS], ro[SCO_BLOCK_ENVS], co[SCO_BLOCK_ENVS];
-        float *phi_s = (float *)malloc(sizeof(float) * (size_t)nb * NF);
-        float *phi_n = (float *)malloc(sizeof(float) * (size_t)nb * NF);
+        st_tab *tab_s = (st_tab *)malloc(sizeof(st_tab) * nb);
+        st_tab *tab_n = (st_tab *)malloc(sizeof(st_tab) * nb);
         td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
         /* ---- phase P: act, physics, bookkeeping, option logic (per env) */
         int env_of[SCO_BLOCK_ENVS];
@@ -512,8 +498,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             option_id[e] = on;
             opt_steps[e] = keep ? opt_steps[e] + 1 : 0;
             ep_steps[e] = dn ? 0 : eps1;
-            state_features(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], phi_s + (size_t)i * NF);
-            state_features(nx, ny, nvx, nvy, phi_n + (size_t)i * NF);
+            state_tables(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], tab_s[i].AB, tab_s[i].CD);
+            state_tables(nx, ny, nvx, nvy, tab_n[i].AB, tab_n[i].CD);
         }
         /* ---- TD passes, VF by VF */
         for (int k = 0; k < n_vf; ++k) {
@@ -529,10 +515,10 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 items[m].cont = cont;
                 ++m;
             }
-            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, phi_s, phi_n, qcache, N, env_of,
+            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, tab_s, tab_n, qcache, N, env_of,
                           P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k]);
         }
-        free(phi_s); free(phi_n); free(items);
+        free(tab_s); free(tab_n); free(items);
     }
     for (int k = 0; k < n_vf; ++k) {
         for (size_t i = 0; i < (size_t)NACT * NF; ++i)

@@ -18,10 +18,7 @@ extern "C" {
 
 #define SCO_NACT 5
 #define SCO_NF 1296
-#define SCO_BLOCK_ENVS 256          /* largest block geometry supported (array bound) */
-#define SCO_WAVES 8
-#define SCO_BLOCK_ENVS_DEFAULT 128  /* SPEC §5 */
-#define SCO_WAVES_DEFAULT 4
+#define SCO_BLOCK_ENVS 128          /* SPEC §5: envs per block */
 #define SCO_CLF_STRIDE 8
 
 typedef struct {
@@ -48,11 +45,9 @@ typedef struct {
     int32_t parents[8];         /* SPEC §4.2 option graph: target option of k (0 = goal); [0] unused */
 } sco_params;
 
-void sco_set_geometry(int block_envs, int waves);   /* SPEC §5 geometry of the build under test */
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void sco_sincospi(float t, float *c, float *s);
 float sco_sigmoid(float z);
-int sco_feature_index(int lane, int slot);   /* canonical wave order, -1 if the slot is empty */
 
 /* SPEC §1.3 for n independent envs with given actions; no reset, no bookkeeping. */
 void sco_pinball_step(const sco_params *p, int n, float *x, float *y, float *vx, float *vy,

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsc_oracle.so")
-NACT, NF, CLF_STRIDE, BLOCK_ENVS, WAVES = 5, 1296, 8, 128, 4
+NACT, NF, CLF_STRIDE, BLOCK_ENVS = 5, 1296, 8, 128
 
 
 class Params(C.Structure):
@@ -49,14 +49,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.sco_sigmoid.restype = C.c_float
         _lib.sco_sigmoid.argtypes = [C.c_float]
-        _lib.sco_feature_index.restype = C.c_int
         _lib.sco_q_update_grad.restype = C.c_int
-        try:      # follow the geometry of the HIP library under test (SPEC §5), if it has been built
-            import skill_chaining_with_graphs_amd as _scg
-            be = _scg.load_library().scg_block_envs()
-            _lib.sco_set_geometry(be, be // 32)
-        except Exception:
-            pass
     return _lib
 
 
@@ -103,9 +96,6 @@ class Oracle:
 
     def sigmoid(self, z):
         return float(self.L.sco_sigmoid(C.c_float(z)))
-
-    def feature_index(self, lane, slot):
-        return int(self.L.sco_feature_index(lane, slot))
 
     # ---- un-fused entry points (arrays are modified in place like the C-ABI)
     def pinball_step(self, x, y, vx, vy, action):

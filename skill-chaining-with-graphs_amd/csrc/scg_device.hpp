@@ -10,11 +10,7 @@ namespace scg {
 
 constexpr int NACT = 5;
 constexpr int NF = 1296;
-constexpr int NSLOT = 21;          // feature slots per lane (SPEC §3.1)
-#ifndef SCG_BLOCK_ENVS
-#define SCG_BLOCK_ENVS 128
-#endif
-constexpr int BLOCK_ENVS = SCG_BLOCK_ENVS;    // SPEC §5 geometry: envs per workgroup (128; `make b256` builds the 256-env variant)
+constexpr int BLOCK_ENVS = 128;               // SPEC §5 geometry: envs per block = per workgroup
 constexpr int WAVES = BLOCK_ENVS / 32;        // 32 envs per wavefront in phase P
 constexpr int LIST_WAVES = BLOCK_ENVS / 64;   // waves that ballot the workgroup's env flags
 constexpr int THREADS = WAVES * 64;
@@ -78,7 +74,7 @@ __device__ __forceinline__ float2 pow_at(const float2 *pw, int d, int k) {   // 
     return k == 0 ? make_float2(1.0f, 0.0f) : v;
 }
 
-// ------------------------------------------------------------------ SPEC §3.1 butterfly
+// ------------------------------------------------------------------ 64-lane butterfly (SPEC §6)
 // for m in (1,2,4,8,16,32): v_l = v_l + v_(l xor m). Stages 1..8 are DPP adds inside a 16-lane row
 // (after stages 1,2 a quad is uniform, so row_half_mirror == xor 4; after stage 4, row_mirror == xor 8);
 // stages 16 and 32 use gfx950's v_permlane16_swap / v_permlane32_swap: with both operands = v they return
@@ -95,65 +91,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// the same butterfly for N independent values, stage by stage (N independent chains hide the DPP hazards)
-template <int N>
-__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0xB1, 0xF, 0xF, true));
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0x4E, 0xF, 0xF, true));
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0x141, 0xF, 0xF, true));
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[i]), 0x140, 0xF, 0xF, true));
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
-        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-}
-
-// ---- transposed butterflies (same pairing tree as wave_sum: stages xor 1, 2, 4, 8, 16, 32; only the
-// lanes that end up holding each sum differ). Lanes exchange HALF of their values at the first two
-// stages instead of all of them: after xor-1 and xor-2 lane l holds the quad-complete partial sums of
-// item (l & 3) only, so the remaining four stages run on a quarter of the values.
-__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
-__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }
 __device__ __forceinline__ float swz_xor4(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)); }
-__device__ __forceinline__ float swz_xor8(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x201F)); }
-
-// in: v[4*M] = M values for each of 4 items (item-major). out: o[M] = full 64-lane sums of item (lane & 3).
-template <int M>
-__device__ __forceinline__ void quad_transposed_sum(const float (&v)[4 * M], float (&o)[M], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float r0[M], r1[M];
-#pragma unroll
-    for (int a = 0; a < M; ++a) {      // xor 1: items 0<->1 and 2<->3
-        r0[a] = (b0 ? v[M + a] : v[a]) + dpp_xor1(b0 ? v[a] : v[M + a]);
-        r1[a] = (b0 ? v[3 * M + a] : v[2 * M + a]) + dpp_xor1(b0 ? v[2 * M + a] : v[3 * M + a]);
-    }
-#pragma unroll
-    for (int a = 0; a < M; ++a) o[a] = (b1 ? r1[a] : r0[a]) + dpp_xor2(b1 ? r0[a] : r1[a]);   // xor 2
-#pragma unroll
-    for (int a = 0; a < M; ++a) o[a] = o[a] + swz_xor4(o[a]);
-#pragma unroll
-    for (int a = 0; a < M; ++a) o[a] = o[a] + swz_xor8(o[a]);
-#pragma unroll
-    for (int a = 0; a < M; ++a) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[a]), __float_as_uint(o[a]), false, false);
-        o[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-#pragma unroll
-    for (int a = 0; a < M; ++a) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[a]), __float_as_uint(o[a]), false, false);
-        o[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-}
 
 // ------------------------------------------------------------------ SPEC §1.3
 struct MapScalars {

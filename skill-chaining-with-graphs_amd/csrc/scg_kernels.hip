@@ -1,15 +1,20 @@
 // scg_kernels.hip — gfx950 kernels + the C-ABI of include/scg_abi.h.
 //
-// One step-batch (SPEC §5) = sort_hist + sort_scatter (env order) -> td_kernel<FUSED> -> reduce1 -> reduce2.
-// td_kernel: a workgroup = 8 wavefronts owns 256 consecutive positions of the option-sorted env order.
+// One step-batch (SPEC §5) = td_kernel<FUSED> -> reduce_kernel (+ sort_hist / sort_scatter when no env order is
+// prepared). td_kernel: a workgroup = 4 wavefronts owns 128 consecutive positions of the option-sorted env order.
 //   phase P  (one lane per env)       act from qcache, Pinball physics (cell mask -> exact refine -> up to
 //                                     three candidate edges in registers), reset/bookkeeping, option logic
-//   phase Z  (one lane per env-state) unit-complex powers Z_d^k of s and s_next -> LDS
-//   phase TD (one lane per 21 features, four items per wave-iteration), value function by value function:
-//            lists by ballot -> loop A: Q_k(s_next,.) with W_k in 105 VGPRs, packed-fp32 FMAs, transposed
-//            butterflies -> loop BC per action run: Q_k(s,a) -> TD error -> accumulate (one W row + the
-//            105-VGPR accumulator) -> chunked cross-wave reduction through LDS -> the block's slab
-//   reduce1/2  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G
+//   phase Z  (one lane per env-state) Z_d^1 = sincospi of the four normalised state variables of s and s_next -> LDS
+//   phase TD, value function by value function, on the matrix pipe (v_mfma_f32_16x16x4_f32 is bit for bit a k-ordered
+//            fmaf chain, so the CPU oracle reproduces every sum):
+//     E   Q_k(s_next, .) of 8 items per wave-iteration: T[(a,c12)][item re|im] = W_k (180 x 36, resident in 108
+//         VGPRs as A operands) x CD (36 x 16, from a per-wave LDS table) = 108 MFMAs, then per lane 48 fmas with the
+//         AB factors and a 3-stage butterfly (SPEC §3.1)
+//     U1  Q_k(s, a_t) per action run, 32 items at a time: the same contraction on the 3 row tiles of action a_t
+//     U2  the block partial G_b,k[a] (36 x 36) += P (36 x 2n, delta-scaled AB factors) x C^T (2n x 36, CD factors):
+//         9 output tiles per action dealt over the 4 waves, accumulators stay in registers for the whole pass and
+//         go straight to the block's slab (no cross-wave reduction)
+//   reduce_kernel  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G; commit + next env order
 // Every sum has the pinned order of SPEC §3.1 / §5 (no atomics on data): the CPU oracle reproduces every bit.
 // No upstream code exists to cite (reference = README.md:1-2); sections cite SPEC.md.
 #include "scg_device.hpp"
@@ -23,31 +28,33 @@
 #include <vector>
 
 using namespace scg;
-typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // LDS map of the step kernel (bytes)
 constexpr int OFF_EDGES = 0;                                   // float[256][8]
-constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][256], sn[4][256]
-constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [256]
-constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [256] (+pad)
-constexpr int OFF_POW = OFF_INT + 4 * BLOCK_ENVS;              // float2 pow[256][2][20]
-constexpr int TAB_FLOATS = 72 * 8;                             // one table buffer: 72 entries x {x[4], y[4]}
-constexpr int SCR_WAVE_FLOATS = 2 * TAB_FLOATS > 15 * 64 ? 2 * TAB_FLOATS : 15 * 64;   // table buffers / reduction parking
-constexpr int SCR_BYTES = WAVES * SCR_WAVE_FLOATS * 4;         // per wave two table buffers (36 KB at 8 waves)
-constexpr int POW_N = 21;                                      // Z_d^1..5 for d = 0..3, then (1,0)
-constexpr int OFF_BUF = OFF_POW + BLOCK_ENVS * 2 * POW_N * 8;  // float buf[5*1296] ALIASES the table scratch
-constexpr bool STAGE_W_LDS = BLOCK_ENVS >= 256;                // 128-env workgroups fetch W_k straight into registers
-constexpr int BUF_BYTES = (!STAGE_W_LDS || SCR_BYTES > NACT * NF * 4) ? SCR_BYTES : NACT * NF * 4;
-constexpr int OFF_ELIST = OFF_BUF + BUF_BYTES;                 // uint16 eval list[256]
-constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[256] (5 action runs)
-constexpr int OFF_MAXQ = OFF_ULIST + BLOCK_ENVS * 2;           // float maxq[256] (per env)
-constexpr int OFF_ENV = OFF_MAXQ + BLOCK_ENVS * 4;             // int env[256]: env index of each block slot
+constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][128], sn[4][128]
+constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [128]
+constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [128] (+pad)
+constexpr int OFF_Z1 = OFF_INT + 4 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
+// region R, used by one phase at a time:
+//   E : per wave CDk[36][16] + ABq[16][36] floats                       (4 x 4608 B)
+//   U : CDT[36][US] (CD factors, c34 major), ABq[64][36], PT[36][US]    (one chunk of <= 32 items = 64 K-steps)
+constexpr int E_TAB_FLOATS = 36 * 16 + 16 * 36;
+constexpr int US = 68;                                         // row stride of the chunk tables (floats)
+constexpr int U_CDT = 0, U_ABQ = 36 * US, U_PT = U_ABQ + 64 * 36, U_FLOATS = U_PT + 36 * US;
+constexpr int R_FLOATS = WAVES * E_TAB_FLOATS > U_FLOATS ? WAVES * E_TAB_FLOATS : U_FLOATS;
+constexpr int OFF_R = OFF_Z1 + BLOCK_ENVS * 2 * 4 * 8;
+constexpr int OFF_ELIST = OFF_R + R_FLOATS * 4;                // uint16 eval list[128]
+constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[128] (5 action runs)
+constexpr int OFF_MAXQ = OFF_ULIST + BLOCK_ENVS * 2;           // float maxq[128] (per env)
+constexpr int OFF_DELTA = OFF_MAXQ + BLOCK_ENVS * 4;           // float delta[32] (per chunk slot)
+constexpr int OFF_ENV = OFF_DELTA + 32 * 4;                    // int env[128]: env index of each block slot
 constexpr int OFF_CLF = OFF_ENV + BLOCK_ENVS * 4;              // float clf[6][8]
 constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[32]
 constexpr int LDS_BYTES = OFF_MISC + 128;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(OFF_POW % 16 == 0 && OFF_BUF % 16 == 0, "LDS alignment");
+static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
+static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0, "LDS alignment");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
@@ -67,19 +74,8 @@ enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 #define SCG_STAMP(SEC) do { } while (0)
 #endif
 
-// global stores of per-step outputs: SCG_NT=1 marks them non-temporal (stream out of L2 during the kernel
-// instead of being written back at the end-of-kernel release)
-#ifndef SCG_NT
-#define SCG_NT 0
-#endif
 template <typename T>
-__device__ __forceinline__ void gstore(T *p, T v) {
-#if SCG_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void gstore(T *p, T v) { *p = v; }
 
 struct StepArgs {
     // env state (FUSED: in/out; TRANS/QVAL: in)
@@ -125,18 +121,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // Workgroup barrier for LDS hand-offs only. __syncthreads() carries a workgroup-scope release fence, which on
-// gfx9 means s_waitcnt vmcnt(0): every barrier after a global store waits for the store to be acknowledged
-// (≈ 9 us after phase P's scattered state stores, and again after every slab chunk). Nothing in td_kernel
-// passes data between threads through global memory, so the barriers only need this wave's LDS traffic done.
-#ifndef SCG_LDS_BARRIER
-#define SCG_LDS_BARRIER 1
-#endif
+// gfx9 means s_waitcnt vmcnt(0): every barrier after a global store waits for the store to be acknowledged.
+// Nothing in td_kernel passes data between threads through global memory, so the barriers only need this wave's
+// LDS traffic done.
 __device__ __forceinline__ void block_lds_sync() {
-#if SCG_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 
 __device__ __forceinline__ bool in_set(const StepArgs &A, int k, float x, float y) {
@@ -145,23 +134,67 @@ __device__ __forceinline__ bool in_set(const StepArgs &A, int k, float x, float 
     return clf_z(A.clf + CLF_STRIDE * k, x, y) > 0.0f;
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
+// ------------------------------------------------------------------------------------------------
+// SPEC §3 tables of one item from its four Z_d^1 (z1p: 4 float2 in LDS). The calling lane owns second index
+// `cp` (c2 of AB, c4 of CD; cp < 6) and gets, for the first index c = 0..5, AB[6c + cp] and CD[6c + cp]:
+// AB[c1*6 + c2] = cmul(Z_0^c1, Z_1^c2), CD[c3*6 + c4] = cmul(Z_2^c3, Z_3^c4), Z^0 = (1, 0), Z^k = cmul(Z^(k-1), Z^1).
+__device__ __forceinline__ float2 zpow_sel(float2 z, int c) {
+    float2 cur = z, out = make_float2(1.0f, 0.0f);
+#pragma unroll
+    for (int j = 1; j <= 5; ++j) {
+        if (c == j) out = cur;
+        if (j < 5) cur = cmul(cur, z);
+    }
+    return out;
+}
+__device__ __forceinline__ void item_entries(const float2 *z1p, int cp, float2 (&ab)[6], float2 (&cd)[6]) {
+    const float4 za = *reinterpret_cast<const float4 *>(z1p), zc = *reinterpret_cast<const float4 *>(z1p + 2);
+    const float2 z0 = make_float2(za.x, za.y), z1 = make_float2(za.z, za.w);
+    const float2 z2 = make_float2(zc.x, zc.y), z3 = make_float2(zc.z, zc.w);
+    const float2 pb = zpow_sel(z1, cp), pd = zpow_sel(z3, cp);
+    float2 pa = make_float2(1.0f, 0.0f), pc = make_float2(1.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        if (c == 1) { pa = z0; pc = z2; }
+        if (c > 1) { pa = cmul(pa, z0); pc = cmul(pc, z2); }
+        ab[c] = cmul(pa, pb);
+        cd[c] = cmul(pc, pd);
+    }
+}
+
+// SPEC §3.1 butterfly over the 16 partial sums of one item (4 row groups x re|im, the item's 8 columns hold
+// [re x 4 items, im x 4 items]): u_g = q_re + q_im (lane xor 4), then (u_0 + u_1) + (u_2 + u_3) (lane xor 16, 32)
+template <int M>
+__device__ __forceinline__ void item_tree_sum(float (&q)[M]) {
+#pragma unroll
+    for (int a = 0; a < M; ++a) q[a] = q[a] + swz_xor4(q[a]);
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(q[a]), __float_as_uint(q[a]), false, false);
+        q[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[a]), __float_as_uint(q[a]), false, false);
+        q[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_edges = reinterpret_cast<float *>(smem + OFF_EDGES);
-    float *s_s = reinterpret_cast<float *>(smem + OFF_S);              // [8][256]: s then sn
+    float *s_s = reinterpret_cast<float *>(smem + OFF_S);              // [8][128]: s then sn
     float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
     float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
     uint8_t *s_a = reinterpret_cast<uint8_t *>(smem + OFF_INT);
     uint8_t *s_ot = s_a + BLOCK_ENVS, *s_on = s_ot + BLOCK_ENVS;
-    float2 *s_pow = reinterpret_cast<float2 *>(smem + OFF_POW);
-    float *s_scr = reinterpret_cast<float *>(smem + OFF_BUF);          // table scratch, aliases s_buf
-    float *s_buf = reinterpret_cast<float *>(smem + OFF_BUF);
+    float2 *s_z1 = reinterpret_cast<float2 *>(smem + OFF_Z1);
+    float *s_R = reinterpret_cast<float *>(smem + OFF_R);
     uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
     uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
     float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
+    float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
     int *s_env = reinterpret_cast<int *>(smem + OFF_ENV);
     float *s_clf = reinterpret_cast<float *>(smem + OFF_CLF);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
@@ -183,7 +216,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     }
 
     // ------------------------------------------------------------------ phase P
-    if (lane < 32) {                                  // 8 waves x 32 lanes: two waves per SIMD hide LDS latency
+    if (lane < 32) {                                  // 4 waves x 32 lanes
         const int i = wave * 32 + lane;
         const int e = (MODE == MODE_FUSED && A.perm && i < nb) ? A.perm[e0 + i] : e0 + i;
         s_env[i] = e;
@@ -294,167 +327,32 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
-    // ------------------------------------------------------------------ phase Z (SPEC §3)
+    // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s and s_next
     {
         const int i = tid & (BLOCK_ENVS - 1), sg = tid / BLOCK_ENVS;
         if (i < nb && (MODE != MODE_QVAL || sg == 1)) {
             const float *st = s_s + sg * 4 * BLOCK_ENVS;
-            state_powers(st[i], st[BLOCK_ENVS + i], st[2 * BLOCK_ENVS + i], st[3 * BLOCK_ENVS + i],
-                         s_pow + (i * 2 + sg) * POW_N);
-            s_pow[(i * 2 + sg) * POW_N + 20] = make_float2(1.0f, 0.0f);     // Z^0, so k = 0 needs no select
+            const float sv0 = st[i], sv1 = st[BLOCK_ENVS + i];
+            const float sv2 = fmaf(st[2 * BLOCK_ENVS + i], 0.25f, 0.5f), sv3 = fmaf(st[3 * BLOCK_ENVS + i], 0.25f, 0.5f);
+            const float2 za = sincospi_cs(sv0), zb = sincospi_cs(sv1), zc = sincospi_cs(sv2), zd = sincospi_cs(sv3);
+            float4 *dst = reinterpret_cast<float4 *>(s_z1 + (i * 2 + sg) * 4);
+            dst[0] = make_float4(za.x, za.y, zb.x, zb.y);
+            dst[1] = make_float4(zc.x, zc.y, zd.x, zd.y);
         }
     }
 
-    // ------------------------------------------------------------------ phase TD (SPEC §5)
-    // One lane per 21 features; each wave handles GI = 4 items per iteration so that table building,
-    // LDS reads, control flow and the butterflies are amortised over four items, and the FMAs run as
-    // packed-fp32 over item pairs. Canonical orders are untouched: item -> wave by list position mod 8,
-    // every dot product is one fma chain over slots 0..20 per lane, items accumulate in list order.
-    constexpr int GI = 4;
-    // Optional (-DSCG_MFMA=1, `make mfma`): slots 0..15 of every item's phi from one v_mfma_f32_32x32x2_f32 per item
-    // (SPEC §3.1's slot order is that instruction's accumulator layout and its result is bit-identical to the VALU
-    // formula — tools/mfma_phi_exact.hip; the parity suite passes with it). Off by default: it removes ~22 % of the
-    // slot loops' VALU instructions, but each MFMA holds the SIMD for 64 cycles and measured 164.7 vs 157.8 us per
-    // step.
-#ifndef SCG_MFMA
-#define SCG_MFMA 0
-#endif
-    constexpr bool USE_MFMA = SCG_MFMA != 0;
-    const int hi = lane >> 5, col = lane & 31;
-    const int tl = lane >> 2;                             // tail row part: c12 = 16 t + tl
-    const bool v20 = lane < 16;                           // slot 20 holds a feature only in lanes 0..15
-    const float m20 = v20 ? 1.0f : 0.0f;
-
-    // scratch tables: per wave 2 buffers x 72 entries (AB 0..35, CD 36..71) x {x[4 items], y[4 items]}
-    float *scr0 = s_scr + wave * SCR_WAVE_FLOATS;
-    const float4 *t_m0 = reinterpret_cast<const float4 *>(scr0) + 2 * hi;                    // slots 16, 17: [4j], [4j+1]
-    const float4 *t_q0 = reinterpret_cast<const float4 *>(scr0) + 8 * hi;                    // slots 0..15: entry 8(j>>2) + 4 hi + (j&3)
-    const float4 *t_a0 = reinterpret_cast<const float4 *>(scr0) + 2 * col + hi;              // MFMA A operand: AB entry col, x or y
-    const float4 *t_t0 = reinterpret_cast<const float4 *>(scr0) + 2 * tl;                    // [32t], [32t+1]
-    const float4 *t_t20 = reinterpret_cast<const float4 *>(scr0) + 2 * min(32 + tl, 35);
-    const float4 *t_cm0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + col);
-    const float4 *t_ct0 = reinterpret_cast<const float4 *>(scr0) + 2 * (36 + 32 + (lane & 3));
-    float *buf_m = s_buf + hi * 36 + col;                 // slots 16, 17: buf_m[a*NF + 72j]
-    float *buf_q = s_buf + hi * 144 + col;                // slots 0..15: buf_q[a*NF + 36 (8(j>>2) + (j&3))]
-    float *buf_t = s_buf + tl * 36 + 32 + (lane & 3);     // buf_t[a*NF + 576t]
-
-    // table building: lane l owns entry l (round 0) and, for l < 8, entry 64 + l (round 1) of all 4 items.
-    // Entry e < 36: AB = Z_0^(e/6) * Z_1^(e%6); e >= 36: CD = Z_2^(q/6) * Z_3^(q%6), q = e - 36. Offsets into
-    // a state's 21-entry power table (entry 20 = Z^0), in float2 units.
-    auto pow_off = [](int d, int kk) { return kk > 0 ? d * 5 + kk - 1 : 20; };
-    int goa[2], gob[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int e = 64 * r + lane;
-        const int qd = e < 36 ? e : e - 36, d0 = e < 36 ? 0 : 2;
-        const int ka = (qd / 6) % 6, kb = qd % 6;
-        goa[r] = pow_off(d0, ka); gob[r] = pow_off(d0 + 1, kb);
-    }
-    auto gen_tables = [&](const int (&ie)[GI], int sg, float *dst) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            if (r == 0 || lane < 8) {
-                float zx[GI], zy[GI];
-#pragma unroll
-                for (int g = 0; g < GI; ++g) {
-                    const float2 *pw = s_pow + (ie[g] * 2 + sg) * POW_N;
-                    const float2 z = cmul(pw[goa[r]], pw[gob[r]]);
-                    zx[g] = z.x; zy[g] = (64 * r + lane < 36) ? -z.y : z.y;   // AB entries hold -Im: phi = fma(-Im ab, Im cd, ..) needs no sign flip
-                }
-                float4 *d4 = reinterpret_cast<float4 *>(dst) + 2 * (64 * r + lane);
-                d4[0] = make_float4(zx[0], zx[1], zx[2], zx[3]);
-                d4[1] = make_float4(zy[0], zy[1], zy[2], zy[3]);
-            }
-        }
-    };
-    // quad descriptor: list entries [i0, i0 + 4) (block-local env indices); a missing entry repeats the first
-    auto load_group = [&](const uint16_t *lst, int cnt, int i0, int (&ie)[GI], bool (&ok)[GI]) {
-#pragma unroll
-        for (int g = 0; g < GI; ++g) {
-            ok[g] = i0 + g < cnt;
-            ie[g] = __builtin_amdgcn_readfirstlane((int)lst[ok[g] ? i0 + g : i0]);
-        }
-    };
-
-    const uint32_t w_vm = (uint32_t)(hi * 36 + col) * 4u; // W byte offsets of the lane's slots 16-17 / 0-15 / tail
-    const uint32_t w_vq = (uint32_t)(hi * 144 + col) * 4u;
-    const uint32_t w_vt = (uint32_t)(tl * 36 + 32 + (lane & 3)) * 4u;
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(A.W), 0, (MODE == MODE_QVAL ? 1 : A.n_vf) * NACT * NF * 4, 0x00020000);
-
-    // R = W_k in loop A (the accumulator of loop BC reuses its registers). Stored as action
-    // pairs (a0,a1), (a2,a3) + a4 so that loop A's packed FMAs take real register pairs: a {w,w} splat
-    // operand costs a second VGPR per weight once hipcc hoists it out of the group loop (it did: 2 x 105).
-    v2f Rp[2][NSLOT];
-    v2f R4p[(NSLOT + 1) / 2];                   // action 4 as slot pairs (j, j+1)
-#define SCG_R4(J) (((J) & 1) ? R4p[(J) >> 1].y : R4p[(J) >> 1].x)
-#define SCG_R(AA, J) ((AA) == 0 ? Rp[0][J].x : (AA) == 1 ? Rp[0][J].y : (AA) == 2 ? Rp[1][J].x : (AA) == 3 ? Rp[1][J].y : SCG_R4(J))
-#define SCG_R_SET(AA, J, V)                                                                     \
-    do {                                                                                        \
-        if ((AA) == 0) Rp[0][J].x = (V); else if ((AA) == 1) Rp[0][J].y = (V);                  \
-        else if ((AA) == 2) Rp[1][J].x = (V); else if ((AA) == 3) Rp[1][J].y = (V);               \
-        else if ((J) & 1) R4p[(J) >> 1].y = (V); else R4p[(J) >> 1].x = (V);                    \
-    } while (0)
-
-// table reads of slot J (compile-time J): x[4] / y[4] of the slot's AB entry
-#define SCG_QOFF(J) (8 * ((J) >> 2) + ((J) & 3))              /* slots 0..15 (SPEC §3.1): c12 = SCG_QOFF(j) + 4 hi */
-#define SCG_LDX(J) ((J) < 16 ? t_q[2 * SCG_QOFF(J)] : (J) < 18 ? t_m[4 * (J)] : ((J) < 20 ? t_t[32 * ((J)-18)] : t_t2[0]))
-#define SCG_LDY(J) ((J) < 16 ? t_q[2 * SCG_QOFF(J) + 1] : (J) < 18 ? t_m[4 * (J) + 1] : ((J) < 20 ? t_t[32 * ((J)-18) + 1] : t_t2[1]))
-// The slot loop shared by loops A, B and C: for j = 0..20 form phi of the quad's 4 items (pa = items 0,1;
-// pb = items 2,3; packed fp32) from the tables at t_m/t_t/t_t2 and the lane's column factors, then run BODY.
-// Table reads are register-pipelined DEPTH slots ahead and sched_barrier pins that pattern (left alone,
-// hipcc hoists all 42 ds_read_b128 of a quad and spills hundreds of VGPRs). Loop A is register-bound
-// (DEPTH 1); loops B and C have only ~7 instructions per slot, so they run 4 slots ahead.
-#define SCG_SLOT_LOOP_DS(DEPTH, J0, ...)                                                                \
-    {                                                                                                   \
-        float4 axq[DEPTH + 1], ayq[DEPTH + 1];                                                          \
-        _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = SCG_LDX((J0) + d_); ayq[d_] = SCG_LDY((J0) + d_); } \
-        _Pragma("unroll") for (int j = (J0); j < NSLOT; ++j) {                                          \
-            if (j + DEPTH < NSLOT) { axq[DEPTH] = SCG_LDX(j + DEPTH); ayq[DEPTH] = SCG_LDY(j + DEPTH); } \
-            if (j == 18) { ccx = t_ct0[boff]; ccy = t_ct0[boff + 1]; }   /* tail column factor from here on */ \
-            const float4 ax0 = axq[0], ay0 = ayq[0], cx_ = ccx, cy_ = ccy;                              \
-            const v2f ax01 = {ax0.x, ax0.y}, ax23 = {ax0.z, ax0.w}, ay01 = {ay0.x, ay0.y}, ay23 = {ay0.z, ay0.w}; \
-            const v2f cx01 = {cx_.x, cx_.y}, cx23 = {cx_.z, cx_.w}, cy01 = {cy_.x, cy_.y}, cy23 = {cy_.z, cy_.w}; \
-            v2f pa = __builtin_elementwise_fma(ay01, cy01, ax01 * cx01);   /* ay = -Im(AB) */             \
-            v2f pb = __builtin_elementwise_fma(ay23, cy23, ax23 * cx23);                                \
-            if (j == 20) { pa = pa * (v2f){m20, m20}; pb = pb * (v2f){m20, m20}; }                      \
-            { __VA_ARGS__ }                                                                             \
-            _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) { axq[d_] = axq[d_ + 1]; ayq[d_] = ayq[d_ + 1]; } \
-            __builtin_amdgcn_sched_barrier(0);                                                          \
-        }                                                                                               \
-    }
-// With USE_MFMA the slots 0..15 come from the matrix pipe (PHI, see SCG_GROUP_BEGIN) and the loop starts at slot 16.
-#define SCG_J0 (USE_MFMA ? 16 : 0)
-#define SCG_SLOT_LOOP(...) SCG_SLOT_LOOP_DS(1, SCG_J0, __VA_ARGS__)
-#define SCG_SLOT_LOOP4(...) SCG_SLOT_LOOP_DS(2, SCG_J0, __VA_ARGS__)
-#define SCG_MFMA_PAIR(H)                                                                                \
-    {                                                                                                   \
-        const f16v z_ = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; \
-        PHI[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((H) ? av_.z : av_.x, (H) ? bv_.z : bv_.x, z_, 0, 0, 0); \
-        PHI[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((H) ? av_.w : av_.y, (H) ? bv_.w : bv_.y, z_, 0, 0, 0); \
-    }
-// quad prologue: wait for this quad's tables, start the next quad's (index QN, if < NQ), bind table pointers
-#define SCG_GROUP_BEGIN(LST, CNT, QN, NQ, SG)                                                           \
-    const int boff = (par & 1) * (TAB_FLOATS / 4);                                                      \
-    int ne[GI];                                                                                         \
-    bool nok[GI];                                                                                       \
-    wave_lds_sync();                                                                                    \
-    float4 ccx = t_cm0[boff], ccy = t_cm0[boff + 1];          /* the lane's main column factor (slots 0..17) */ \
-    /* phi of slots 0..15: one MFMA per item, two items at a time (32 VGPRs); operands: AB entry `col` as      \
-       Re (lanes < 32) / -Im (lanes >= 32), CD entry `col` as Re / Im, for the quad's 4 items */           \
-    f16v PHI[2];                                                                                        \
-    float4 av_ = ccx, bv_ = ccx;                                                                        \
-    if constexpr (USE_MFMA) {                                                                           \
-        av_ = t_a0[boff];                                                                               \
-        bv_ = hi ? ccy : ccx;                                                                           \
-        SCG_MFMA_PAIR(0)                                       /* runs under the next quad's table build */ \
-    }                                                                                                   \
-    load_group(LST, CNT, 4 * ((QN) < (NQ) ? (QN) : qi), ne, nok);                                       \
-    if ((QN) < (NQ)) gen_tables(ne, SG, scr0 + TAB_FLOATS - boff * 4);                                  \
-    const float4 *t_m = t_m0 + boff, *t_q = t_q0 + boff, *t_t = t_t0 + boff, *t_t2 = t_t20 + boff;
-#define SCG_GROUP_END                                                                                   \
-    _Pragma("unroll") for (int g = 0; g < GI; ++g) { ie[g] = ne[g]; ok[g] = nok[g]; }                   \
-    ++par;
+    // ------------------------------------------------------------------ phase TD (SPEC §3.1, §5) on the matrix pipe
+    // Lane roles. As an MFMA operand lane (16x16x4): n = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
+    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of the
+    // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
+    // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
+    // imaginary-part column at 8 h + 4 + i.
+    const int n16 = lane & 15, g = lane >> 4;
+    const int bi = lane & 7, cp = lane >> 3;
+    const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
+    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
+    const int ocol_part = (n16 >> 2) & 1;                     //               0 = re, 1 = im
+    const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
 
     const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[31]) : ~0u;
     for (int k = A.k_lo; k <= A.k_hi; ++k) {
@@ -464,12 +362,9 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
         block_lds_sync();
         SCG_STAMP(k == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
-        // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 256 envs:
-        //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), env order
-        //   update lists: envs that update VF k, one run per action a_t, env order inside a run
-        // Quads of 4 consecutive list entries are dealt to the waves round-robin (quad q -> wave q mod 8);
-        // an update quad never straddles two actions, so the inner loops are specialised per action and
-        // every accumulator row acc[a] sees exactly its own items.
+        // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 128 envs:
+        //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), block order
+        //   update lists: envs that update VF k, one run per action a_t, block order inside a run
         bool ev = false, up = false;
         int at = -1;
         if (tid < nb) {
@@ -491,23 +386,22 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             }
         }
         block_lds_sync();
-        int n_ev = 0, run_len[NACT], run_off[NACT], qbase[NACT + 1];
+        int n_ev = 0, run_len[NACT], run_off[NACT];
         {
             int se = 0;
 #pragma unroll
             for (int w2 = 0; w2 < LIST_WAVES; ++w2) se += s_misc[w2 * 8];
             n_ev = __builtin_amdgcn_readfirstlane(se);
-            int off = 0, qb = 0;
+            int off = 0;
 #pragma unroll
-            for (int a = 0; a < NACT; ++a) {      // wave-uniform: keep them in SGPRs (16 VGPRs otherwise)
+            for (int a = 0; a < NACT; ++a) {      // wave-uniform: keep them in SGPRs
                 int sr = 0;
 #pragma unroll
                 for (int w2 = 0; w2 < LIST_WAVES; ++w2) sr += s_misc[w2 * 8 + 1 + a];
                 run_len[a] = __builtin_amdgcn_readfirstlane(sr);
-                run_off[a] = off; qbase[a] = qb;
-                off += run_len[a]; qb += (run_len[a] + 3) >> 2;
+                run_off[a] = off;
+                off += run_len[a];
             }
-            qbase[NACT] = qb;
         }
         const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
         if (wave < LIST_WAVES) {
@@ -530,316 +424,249 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         SCG_STAMP(k == 0 ? 1 : 8);    // phase Z (first pass only) + list build
         if (n_ev + nupd == 0) continue;
 
-        // W_k -> LDS once per workgroup (coalesced float4; the staging area is the reduction buffer, idle
-        // here) -> each lane's 105 weights -> registers. Eight waves no longer fetch the same 26 KB each.
-        if constexpr (STAGE_W_LDS) {
-            const float4 *Wk4 = reinterpret_cast<const float4 *>(A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF));
-            float4 *b4 = reinterpret_cast<float4 *>(s_buf);
-            for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) b4[f4] = Wk4[f4];
-            block_lds_sync();
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-#pragma unroll
-                for (int j = 0; j < 18; ++j) SCG_R_SET(a, j, j < 16 ? buf_q[a * NF + 36 * SCG_QOFF(j)] : buf_m[a * NF + 72 * j]);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const float v = buf_t[a * NF + 576 * t];       // lanes >= 16 read a neighbour's weight at t = 2
-                    SCG_R_SET(a, 18 + t, (t < 2 || v20) ? v : 0.0f);
-                }
-            }
-            block_lds_sync();                                       // the staging area becomes table scratch
-        } else {
-            // 128-env workgroups (two per CU): no LDS room for the 26 KB staging area — every wave fetches its
-            // 105 weights per lane through the buffer descriptor (L2-resident)
-            // (waves that get no quad of the eval list skip the fetch: evaluation-only passes — envs ENTERING an option
-            // nobody here runs, 1.6 per workgroup on the bench workload — have one or two quads)
-            const uint32_t kb = (MODE == MODE_QVAL) ? 0u : (uint32_t)k * (NACT * NF * 4);
-            if (wave < ((n_ev + 3) >> 2)) {
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-#pragma unroll
-                for (int j = 0; j < 18; ++j)
-                    SCG_R_SET(a, j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                                        w_rsrc, j < 16 ? w_vq : w_vm,
-                                        kb + (uint32_t)(a * NF + (j < 16 ? 36 * SCG_QOFF(j) : 72 * j)) * 4u, 0)));
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        w_rsrc, (t < 2 || v20) ? w_vt : 0u, kb + (uint32_t)(a * NF + 576 * t) * 4u, 0));
-                    SCG_R_SET(a, 18 + t, (t < 2 || v20) ? v : 0.0f);
-                }
-            }
-            }
-        }
-        SCG_STAMP(k == 0 ? 2 : 9);    // W staging
-        // ---- loop A (W_k live): Q_k(s_next, .) of one quad at a time -> qcache, max -> s_maxq[env]
+        const float *Wk = A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF);
+        // ---- E: Q_k(s_next, .) of the eval list, one 8-item column block per wave-iteration (SPEC §3.1)
         {
-            const int nq = (n_ev + 3) >> 2;
-            if (wave < nq) {
-                int ie[GI], par = 0;
-                bool ok[GI];
-                load_group(s_elist, n_ev, 4 * wave, ie, ok);
-                gen_tables(ie, 1, scr0);
-                for (int qi = wave; qi < nq; qi += WAVES) {
-                    SCG_GROUP_BEGIN(s_elist, n_ev, qi + WAVES, nq, 1)
-                    v2f q01[GI], q23[GI], q4a = {0.0f, 0.0f}, q4b = {0.0f, 0.0f};
+            const int nqe = (n_ev + 7) >> 3;
+            if (wave < nqe) {
+                // A operands: W_k as a 180 x 36 matrix (row = 36 a + c12), 12 row tiles; lane (n16, g) holds, for tile t
+                // and k-block kb, W[16 t + n16][9 g + kb] — nine consecutive floats per tile (rows >= 180 are zero)
+                float Wr[12][9];
 #pragma unroll
-                    for (int g = 0; g < GI; ++g) { q01[g] = (v2f){0.0f, 0.0f}; q23[g] = (v2f){0.0f, 0.0f}; }
-                    // With the matrix pipe, items go in two pairs: slots 0..15 of a pair come out of PHI (two MFMAs), and
-                    // while the second pair's MFMAs run, the first pair's slots 16..20 are done on the VALU. Every item's
-                    // chain still runs over slots 0..20 in order; the (register-limited) PHI holds one pair at a time.
-#define SCG_A_MAIN(H)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                    \
-        _Pragma("unroll") for (int gg = 0; gg < 2; ++gg) {                                              \
-            const float ph = PHI[gg][j];                                                                \
-            const v2f p2 = {ph, ph};                                                                    \
-            q01[2 * (H) + gg] = __builtin_elementwise_fma(Rp[0][j], p2, q01[2 * (H) + gg]);             \
-            q23[2 * (H) + gg] = __builtin_elementwise_fma(Rp[1][j], p2, q23[2 * (H) + gg]);             \
-            q4s[2 * (H) + gg] = fmaf(SCG_R4(j), ph, q4s[2 * (H) + gg]);                                 \
-        }                                                                                               \
-    }
-                    if constexpr (USE_MFMA) {
-                        float q4s[GI] = {0.0f, 0.0f, 0.0f, 0.0f};
-                        SCG_A_MAIN(0)
-                        q4a = (v2f){q4s[0], q4s[1]};
-                        SCG_MFMA_PAIR(1)
-                        SCG_SLOT_LOOP(                                                  // items 0, 1 (pb is dead code here)
-                            const v2f p0 = {pa.x, pa.x}, p1 = {pa.y, pa.y};
-                            q01[0] = __builtin_elementwise_fma(Rp[0][j], p0, q01[0]);
-                            q23[0] = __builtin_elementwise_fma(Rp[1][j], p0, q23[0]);
-                            q01[1] = __builtin_elementwise_fma(Rp[0][j], p1, q01[1]);
-                            q23[1] = __builtin_elementwise_fma(Rp[1][j], p1, q23[1]);
-                            const v2f w4 = {SCG_R4(j), SCG_R4(j)};
-                            q4a = __builtin_elementwise_fma(w4, pa, q4a);)
-                        ccx = t_cm0[boff]; ccy = t_cm0[boff + 1];                       // main column factor again
-                        SCG_A_MAIN(1)
-                        q4b = (v2f){q4s[2], q4s[3]};
-                        SCG_SLOT_LOOP(                                                  // items 2, 3
-                            const v2f p2_ = {pb.x, pb.x}, p3 = {pb.y, pb.y};
-                            q01[2] = __builtin_elementwise_fma(Rp[0][j], p2_, q01[2]);
-                            q23[2] = __builtin_elementwise_fma(Rp[1][j], p2_, q23[2]);
-                            q01[3] = __builtin_elementwise_fma(Rp[0][j], p3, q01[3]);
-                            q23[3] = __builtin_elementwise_fma(Rp[1][j], p3, q23[3]);
-                            const v2f w4 = {SCG_R4(j), SCG_R4(j)};
-                            q4b = __builtin_elementwise_fma(w4, pb, q4b);)
-                    } else {
-                        SCG_SLOT_LOOP(
-                            const float ph[GI] = {pa.x, pa.y, pb.x, pb.y};
-                            _Pragma("unroll") for (int g = 0; g < GI; ++g) {
-                                const v2f p2 = {ph[g], ph[g]};                            // op_sel splat of a pair half
-                                q01[g] = __builtin_elementwise_fma(Rp[0][j], p2, q01[g]);
-                                q23[g] = __builtin_elementwise_fma(Rp[1][j], p2, q23[g]);
-                            }
-                            const v2f w4 = {SCG_R4(j), SCG_R4(j)};                        // action 4: packed over items
-                            q4a = __builtin_elementwise_fma(w4, pa, q4a);
-                            q4b = __builtin_elementwise_fma(w4, pb, q4b);)
-                    }
-#undef SCG_A_MAIN
-                    float qv[GI * NACT];
+                for (int t = 0; t < 12; ++t) {
+                    const int row = 16 * t + n16;
+                    const float *wp = Wk + (row < 180 ? row : 0) * 36 + 9 * g;
 #pragma unroll
-                    for (int g = 0; g < GI; ++g) {
-                        qv[g * NACT + 0] = q01[g].x; qv[g * NACT + 1] = q01[g].y;
-                        qv[g * NACT + 2] = q23[g].x; qv[g * NACT + 3] = q23[g].y;
-                    }
-                    qv[0 * NACT + 4] = q4a.x; qv[1 * NACT + 4] = q4a.y; qv[2 * NACT + 4] = q4b.x; qv[3 * NACT + 4] = q4b.y;
-                    // butterflies, transposed: lane l ends up with the five Q values of item (l & 3)
-                    float qo[NACT];
-                    quad_transposed_sum<NACT>(qv, qo, lane);
-                    {
-                        const int gl = lane & 3;
-                        const int il = gl == 0 ? ie[0] : gl == 1 ? ie[1] : gl == 2 ? ie[2] : ie[3];
-                        const bool okl = gl == 0 ? ok[0] : gl == 1 ? ok[1] : gl == 2 ? ok[2] : ok[3];
-                        if (lane < GI && okl) {
-                            if (s_on[il] == k) {
-                                if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
-                                    float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
-                                    orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
-                                    orec[3].x = qo[4];
-                                } else {
+                    for (int kb = 0; kb < 9; ++kb) { const float v = wp[kb]; Wr[t][kb] = row < 180 ? v : 0.0f; }
+                }
+                SCG_STAMP(k == 0 ? 2 : 9);    // W fetch issued
+                float *cdk = s_R + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;
+                for (int cb = wave; cb < nqe; cb += WAVES) {
+                    // tables of the block's 8 items (a short last block repeats its last item)
+                    if (cp < 6) {
+                        const int it = s_elist[min(8 * cb + bi, n_ev - 1)];
+                        float2 ab[6], cd[6];
+                        item_entries(s_z1 + (it * 2 + 1) * 4, cp, ab, cd);
 #pragma unroll
-                                    for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
-                                }
-                            }
-                            float mx = qo[0];
-#pragma unroll
-                            for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
-                            s_maxq[il] = mx;
+                        for (int c = 0; c < 6; ++c) {
+                            abq[bcol * 36 + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * 36 + 6 * c + cp] = -ab[c].y;
+                            cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
                         }
                     }
-                    SCG_GROUP_END
+                    wave_lds_sync();
+                    float B[9];
+#pragma unroll
+                    for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+                    f4v acc[12];
+#pragma unroll
+                    for (int t = 0; t < 12; ++t) acc[t] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kb = 0; kb < 9; ++kb) {
+#pragma unroll
+                        for (int t = 0; t < 12; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[t][kb], B[kb], acc[t], 0, 0, 0);
+                    }
+                    // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
+                    float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int t = 0; t < 12; ++t) {
+                        const int Ct = (16 * t) % 36, At = (16 * t) / 36;
+                        const bool wrap = Ct + 4 * g >= 36;
+                        const int c0 = Ct + 4 * g - (wrap ? 36 : 0);
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + c0);
+                        if (Ct + 12 < 36) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) q[At] = fmaf(acc[t][v], ab4[v], q[At]);
+                        } else {
+                            float xq = wrap ? q[At + 1] : q[At];
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) xq = fmaf(acc[t][v], ab4[v], xq);
+                            q[At] = wrap ? q[At] : xq;
+                            q[At + 1] = wrap ? xq : q[At + 1];
+                        }
+                    }
+                    float qo[NACT] = {q[0], q[1], q[2], q[3], q[4]};
+                    item_tree_sum<NACT>(qo);
+                    if (out_lane && 8 * cb + ocol_item < n_ev) {
+                        const int il = s_elist[8 * cb + ocol_item];
+                        if (s_on[il] == k) {
+                            if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
+                                float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                                orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                                orec[3].x = qo[4];
+                            } else {
+#pragma unroll
+                                for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
+                            }
+                        }
+                        float mx = qo[0];
+#pragma unroll
+                        for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
+                        s_maxq[il] = mx;
+                    }
+                    wave_lds_sync();
                 }
             }
         }
+        SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
         if (MODE == MODE_QVAL || nupd == 0) continue;
-        SCG_STAMP(k == 0 ? 3 : 10);   // loop A (wave 0's share)
-        block_lds_sync();                                   // s_maxq crosses waves (loop B deals quads differently)
+        block_lds_sync();                                   // s_maxq crosses waves; region R changes hands
+        SCG_STAMP(k == 0 ? 4 : 11);   // wait for the other waves' E
 
-        SCG_STAMP(k == 0 ? 4 : 11);   // wait for the other waves' loop A
-        // ---- loop BC (accumulator live, one row of W_k at a time): for each action run, for this wave's quads:
-        //   pass 1 over the slots: phi(s) -> Q_k(s, a) partials -> butterfly -> TD error delta
-        //   pass 2 over the slots: phi(s) again (same tables, re-read from LDS) -> acc[a][f] = fma(delta, phi, acc)
-        // Specialised per action, the loop needs only row a of W_k (21 VGPRs, re-fetched per run through
-        // the buffer descriptor) next to the 105-VGPR accumulator, so Q(s,a) and the accumulate share one
-        // table build and one loop — they used to be two full loops (B and C) over the same items.
-        float Acc[NACT][NSLOT];
+        // ---- U: per action run, chunks of <= 32 update items (SPEC §5)
+        //   build  tables of the chunk's items (state s): CDT[c34][kap], ABq[kap][c12], kap = 2 j + part
+        //   U1     Q_k(s, a) of 8 items per wave on the 3 row tiles of action a -> delta -> PT[c12][kap] = delta * ABq
+        //   U2     G[a] += PT x CDT^T in groups of 4 items: one MFMA over the 4 real parts, one over the 4 imaginary
+        //          parts; the 9 output tiles of the action are dealt to the waves (tile q -> wave (q - a) & 3)
+        f4v accU[NACT][3];
 #pragma unroll
         for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-            for (int j = 0; j < NSLOT; ++j) Acc[a][j] = 0.0f;
+            for (int s = 0; s < 3; ++s) accU[a][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
         }
-        const uint32_t kbase = (uint32_t)k * (NACT * NF * 4);
-        auto loop_bc = [&](auto aa_c) {
+        float *cdt = s_R + U_CDT, *abqu = s_R + U_ABQ, *pt = s_R + U_PT;
+        auto run_u = [&](auto aa_c) {
             constexpr int AA = decltype(aa_c)::value;
-            const int cnt = run_len[AA], nq = (cnt + 3) >> 2;
+            constexpr int T0 = (36 * AA) / 16;                       // first of the 3 row tiles holding action AA's rows
+            const int cnt = run_len[AA];
+            if (cnt == 0) return;
             const uint16_t *lst = s_ulist + run_off[AA];
-            const int q0 = (wave - qbase[AA]) & (WAVES - 1);          // first quad of this run dealt to this wave
-            if (q0 >= nq) return;
-            v2f Wp[(NSLOT + 1) / 2];                                  // row AA of W_k as slot pairs (real pairs:
-                                                                      // a {w,w} splat would cost 2 VGPRs per weight)
+            const int wq = (wave + AA) & 3;                          // this wave's U2 tiles: wq, wq + 4 (, 8 when wq == 0)
+            for (int c0 = 0; c0 < cnt; c0 += 32) {
+                const int len = min(32, cnt - c0), len4 = (len + 3) & ~3;
+                const bool mine = 8 * wave < len;                    // this wave has items in U1
+                // A operands of action AA's row tiles (L1/L2-resident; issued first so the build covers their latency)
+                float Wt[3][9];
+                if (mine) {
 #pragma unroll
-            for (int j = 0; j < NSLOT; ++j) {
-                float v;
-                if (j < 18) {
-                    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        w_rsrc, j < 16 ? w_vq : w_vm,
-                        kbase + (uint32_t)(AA * NF + (j < 16 ? 36 * SCG_QOFF(j) : 72 * j)) * 4u, 0));
-                } else {
-                    v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        w_rsrc, (j < 20 || v20) ? w_vt : 0u, kbase + (uint32_t)(AA * NF + 576 * (j - 18)) * 4u, 0));
-                    if (j == 20) v = v20 ? v : 0.0f;
+                    for (int tt = 0; tt < 3; ++tt) {
+                        const int row = 16 * (T0 + tt) + n16;
+                        const float *wp = Wk + (row < 180 ? row : 0) * 36 + 9 * g;
+#pragma unroll
+                        for (int kb = 0; kb < 9; ++kb) { const float v = wp[kb]; Wt[tt][kb] = row < 180 ? v : 0.0f; }
+                    }
                 }
-                if (j & 1) Wp[j >> 1].y = v; else Wp[j >> 1].x = v;
-            }
-            Wp[NSLOT / 2].y = 0.0f;
-            int ie[GI], par = 0;
-            bool ok[GI];
-            wave_lds_sync();
-            load_group(lst, cnt, 4 * q0, ie, ok);
-            gen_tables(ie, 0, scr0);
-            for (int qi = q0; qi < nq; qi += WAVES) {
-                SCG_GROUP_BEGIN(lst, cnt, qi + WAVES, nq, 0)
-                const float4 cmx_ = ccx, cmy_ = ccy;                  // main column factor, needed again in pass 2
-                v2f qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
-#define SCG_B_MAIN(H)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                    \
-        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;                                         \
-        qs4[2 * (H)] = fmaf(wj, PHI[0][j], qs4[2 * (H)]);                                               \
-        qs4[2 * (H) + 1] = fmaf(wj, PHI[1][j], qs4[2 * (H) + 1]);                                       \
-    }
-                if constexpr (USE_MFMA) {
-                    float qs4[GI] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    SCG_B_MAIN(0)
-                    qa = (v2f){qs4[0], qs4[1]};
-                    SCG_MFMA_PAIR(1)
-                    SCG_SLOT_LOOP4(
-                        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
-                        const v2f w2 = {wj, wj};
-                        qa = __builtin_elementwise_fma(w2, pa, qa);)
-                    ccx = t_cm0[boff]; ccy = t_cm0[boff + 1];            // main column factor again (re-read: cheaper than 8 VGPRs)
-                    SCG_B_MAIN(1)
-                    qb = (v2f){qs4[2], qs4[3]};
-                    SCG_MFMA_PAIR(0)                                  // items 0, 1 again for pass 2, under the rest of pass 1
-                    SCG_SLOT_LOOP4(
-                        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
-                        const v2f w2 = {wj, wj};
-                        qb = __builtin_elementwise_fma(w2, pb, qb);)
-                } else {
-                    SCG_SLOT_LOOP4(
-                        const float wj = (j & 1) ? Wp[j >> 1].y : Wp[j >> 1].x;
-                        const v2f w2 = {wj, wj};                              // op_sel splat of a pair half
-                        qa = __builtin_elementwise_fma(w2, pa, qa);
-                        qb = __builtin_elementwise_fma(w2, pb, qb);)
-                }
-#undef SCG_B_MAIN
-                const float qs[GI] = {qa.x, qa.y, qb.x, qb.y};
-                float qo[1];
-                quad_transposed_sum<1>(qs, qo, lane);                 // lane l holds Q(s,a) of item (l & 3)
-                float dl[GI];
+                // build: wave w owns chunk slots 8 w .. 8 w + 7
                 {
-                    const int gl = lane & 3;
-                    const int i = gl == 0 ? ie[0] : gl == 1 ? ie[1] : gl == 2 ? ie[2] : ie[3];
-                    const float r = (k == 0) ? s_r0[i] : s_ro[i];
-                    const float cont = (k == 0) ? s_c0[i] : s_co[i];
-                    const float target = cont > 0.0f ? fmaf(cont, s_maxq[i], r) : r;
-                    const float d = target - qo[0];
+                    const int j = 8 * wave + bi;
+                    if (cp < 6 && j < len4) {
+                        if (j < len) {
+                            const int it = lst[c0 + j];
+                            float2 ab[6], cd[6];
+                            item_entries(s_z1 + (it * 2 + 0) * 4, cp, ab, cd);
 #pragma unroll
-                    for (int g = 0; g < GI; ++g)                       // lanes 0..3 -> wave-uniform; padding item: += 0
-                        dl[g] = ok[g] ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), g)) : 0.0f;
+                            for (int c = 0; c < 6; ++c) {
+                                abqu[(2 * j) * 36 + 6 * c + cp] = ab[c].x; abqu[(2 * j + 1) * 36 + 6 * c + cp] = -ab[c].y;
+                                cdt[(6 * c + cp) * US + 2 * j] = cd[c].x; cdt[(6 * c + cp) * US + 2 * j + 1] = cd[c].y;
+                            }
+                        } else {                                     // null item padding the last group of 4
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) { cdt[(6 * c + cp) * US + 2 * j] = 0.0f; cdt[(6 * c + cp) * US + 2 * j + 1] = 0.0f; }
+                        }
+                    }
                 }
-                ccx = cmx_; ccy = cmy_;
-#define SCG_C_MAIN(H)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                    \
-        Acc[AA][j] = fmaf(dl[2 * (H)], PHI[0][j], Acc[AA][j]);                                          \
-        Acc[AA][j] = fmaf(dl[2 * (H) + 1], PHI[1][j], Acc[AA][j]);                                      \
-    }
-                if constexpr (USE_MFMA) {
-                    SCG_C_MAIN(0)
-                    SCG_MFMA_PAIR(1)                                  // items 2, 3 again, under the VALU slots
+                block_lds_sync();                                    // tables visible
+                if (mine) {
+                    const int kap = 2 * (8 * wave + ocol_item) + ocol_part;
+                    float B[9];
+#pragma unroll
+                    for (int kb = 0; kb < 9; ++kb) B[kb] = cdt[(9 * g + kb) * US + kap];
+                    f4v acc[3];
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) acc[tt] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kb = 0; kb < 9; ++kb) {
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt)
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[tt][kb], B[kb], acc[tt], 0, 0, 0);
+                    }
+                    float qs = 0.0f;
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) {
+                        const int r0 = 16 * (T0 + tt) + 4 * g - 36 * AA;       // c12 of the lane's first row, if in [0, 36)
+                        const bool in = r0 >= 0 && r0 < 36;
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(abqu + kap * 36 + (in ? r0 : 0));
+                        float xq = qs;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) xq = fmaf(acc[tt][v], ab4[v], xq);
+                        qs = in ? xq : qs;
+                    }
+                    float qo[1] = {qs};
+                    item_tree_sum<1>(qo);
+                    const int j = 8 * wave + ocol_item;
+                    if (out_lane && j < len) {
+                        const int il = lst[c0 + j];
+                        const float r = (k == 0) ? s_r0[il] : s_ro[il];
+                        const float cont = (k == 0) ? s_c0[il] : s_co[il];
+                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], r) : r;
+                        s_delta[j] = target - qo[0];
+                    }
+                    wave_lds_sync();
+                    // PT[c12][kap] = delta_j * ABq[kap][c12] for this wave's 16 K-steps (null items: +0)
+                    {
+                        const int kp = 16 * wave + n16, jj = kp >> 1;
+                        const bool real = jj < len;
+                        const float d = real ? s_delta[jj] : 0.0f;
+                        if (jj < len4) {
+#pragma unroll
+                            for (int m = 0; m < 9; ++m) {
+                                const int c12 = g + 4 * m;
+                                const float v = real ? abqu[kp * 36 + c12] : 0.0f;
+                                pt[c12 * US + kp] = d * v;
+                            }
+                        }
+                    }
                 }
-                SCG_SLOT_LOOP4(
-                    Acc[AA][j] = fmaf(dl[0], pa.x, Acc[AA][j]);
-                    Acc[AA][j] = fmaf(dl[1], pa.y, Acc[AA][j]);
-                    Acc[AA][j] = fmaf(dl[2], pb.x, Acc[AA][j]);
-                    Acc[AA][j] = fmaf(dl[3], pb.y, Acc[AA][j]);)
-                if constexpr (USE_MFMA) { SCG_C_MAIN(1) }
-#undef SCG_C_MAIN
-                SCG_GROUP_END
+                block_lds_sync();                                    // PT visible
+                {
+                    const int ngrp = len4 >> 2;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const int q = wq + 4 * s;
+                        if (s < 2 || wq == 0) {
+                            const int mi = (q * 11) >> 5, ni = q - 3 * mi;             // q / 3, q % 3 for q <= 8
+                            const float *pa = pt + min(16 * mi + n16, 35) * US + 2 * g;
+                            const float *pb = cdt + min(16 * ni + n16, 35) * US + 2 * g;
+                            for (int gi = 0; gi < ngrp; ++gi) {
+                                const float2 a2 = *reinterpret_cast<const float2 *>(pa + 8 * gi);
+                                const float2 b2 = *reinterpret_cast<const float2 *>(pb + 8 * gi);
+                                accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, accU[AA][s], 0, 0, 0);
+                                accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, accU[AA][s], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                block_lds_sync();                                    // chunk tables free again
             }
         };
-        loop_bc(std::integral_constant<int, 0>{}); loop_bc(std::integral_constant<int, 1>{});
-        loop_bc(std::integral_constant<int, 2>{}); loop_bc(std::integral_constant<int, 3>{});
-        loop_bc(std::integral_constant<int, 4>{});
-        SCG_STAMP(k == 0 ? 6 : 13);   // loop C
-        // block partial P = ((acc_0 + acc_1) + ...) + acc_7 (SPEC §5), three slots at a time: every wave
-        // parks its 15 values per lane (5 actions x 3 slots) in the table scratch, then each of the 512
-        // threads adds the 8 waves' values of ~2 outputs in wave order and stores them straight into the
-        // block's slab. (The first version took 8 sequential wave turns of 105 LDS read-modify-writes:
-        // 37k cycles per pass, a third of the kernel.)
+        run_u(std::integral_constant<int, 0>{}); run_u(std::integral_constant<int, 1>{});
+        run_u(std::integral_constant<int, 2>{}); run_u(std::integral_constant<int, 3>{});
+        run_u(std::integral_constant<int, 4>{});
+        SCG_STAMP(k == 0 ? 6 : 13);   // U
+        // ---- the block partial P_b,k straight from the accumulators: tile (mi, ni) of action a, register v of lane
+        // (n16, g) = G[a][16 mi + 4 g + v][16 ni + n16]
         {
             float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
-            float *park = s_scr + wave * SCR_WAVE_FLOATS + lane;       // [wave][15][64]
 #pragma unroll
-            for (int c = 0; c < NSLOT / 3; ++c) {
-                block_lds_sync();                                       // scratch free (tables / previous chunk)
+            for (int a = 0; a < NACT; ++a) {
+                const int wq = (wave + a) & 3;
 #pragma unroll
-                for (int a = 0; a < NACT; ++a) {
+                for (int s = 0; s < 3; ++s) {
+                    const int q = wq + 4 * s;
+                    if (s < 2 || wq == 0) {
+                        const int mi = (q * 11) >> 5, ni = q - 3 * mi;
+                        const int c34 = 16 * ni + n16;
 #pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) park[(a * 3 + jj) * 64] = Acc[a][3 * c + jj];
-                }
-                block_lds_sync();
-                for (int o = tid; o < 15 * 64; o += THREADS) {
-                    const int l = o & 63, v15 = o >> 6;
-                    const int a = v15 / 3, j = 3 * c + (v15 - 3 * a);
-                    float sum = s_scr[o];
-#pragma unroll
-                    for (int w = 1; w < WAVES; ++w) sum = sum + s_scr[w * SCR_WAVE_FLOATS + o];
-                    // canonical feature index of (lane l, slot j) — SPEC §3.1
-                    int f = -1;
-                    if (j < 16) f = (SCG_QOFF(j) + 4 * (l >> 5)) * 36 + (l & 31);
-                    else if (j < 18) f = (2 * j + (l >> 5)) * 36 + (l & 31);
-                    else {
-                        const int idx = 64 * (j - 18) + l;
-                        if (idx < 144) f = (idx >> 2) * 36 + 32 + (idx & 3);
+                        for (int v = 0; v < 4; ++v) {
+                            const int c12 = 16 * mi + 4 * g + v;
+                            if (c12 < 36 && c34 < 36) gstore(&slab[a * NF + c12 * 36 + c34], accU[a][s][v]);
+                        }
                     }
-                    if (f >= 0) gstore(&slab[a * NF + f], sum);
                 }
             }
         }
-        SCG_STAMP(k == 0 ? 7 : 14);   // block reduction + slab store
+        SCG_STAMP(k == 0 ? 7 : 14);   // slab store
     }
-#undef SCG_LDX
-#undef SCG_QOFF
-#undef SCG_LDY
-#undef SCG_SLOT_LOOP
-#undef SCG_SLOT_LOOP4
-#undef SCG_SLOT_LOOP_DS
-#undef SCG_J0
-#undef SCG_GROUP_BEGIN
-#undef SCG_MFMA_PAIR
-#undef SCG_GROUP_END
-#undef SCG_R
-#undef SCG_R_SET
-#undef SCG_R4
 }
 
 // ------------------------------------------------------------------------------------------------
