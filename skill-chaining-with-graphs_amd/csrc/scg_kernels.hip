@@ -37,24 +37,26 @@ constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][128
 constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [128]
 constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [128] (+pad)
 constexpr int OFF_Z1 = OFF_INT + 4 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
-// region R, used by one phase at a time:
-//   E : per wave CDk[36][16] + ABq[16][36] floats                       (4 x 4608 B)
-//   U : CDT[36][US] (CD factors, c34 major), ABq[64][36], PT[36][US]    (one chunk of <= 32 items = 64 K-steps)
+// region W: W_k staged in A-operand order (12 tiles x 9 k-blocks x 64 lanes), read once per wave per pass
+// region R, used by one phase at a time (R reaches back over region W, which is dead once the A operands are in registers):
+//   E, U1 : per wave CDk[36][16] + ABq[16][36] floats (4 x 4608 B), behind region W
+//   U2    : PT[36][US], CDT[36][US] (one chunk of 64 padded slots = 128 K-steps), from the start of region W
+constexpr int W_FLOATS = 12 * 9 * 64;
 constexpr int E_TAB_FLOATS = 36 * 16 + 16 * 36;
-constexpr int US = 68;                                         // row stride of the chunk tables (floats)
-constexpr int U_CDT = 0, U_ABQ = 36 * US, U_PT = U_ABQ + 64 * 36, U_FLOATS = U_PT + 36 * US;
-constexpr int R_FLOATS = WAVES * E_TAB_FLOATS > U_FLOATS ? WAVES * E_TAB_FLOATS : U_FLOATS;
+constexpr int US = 132;                                        // row stride of the chunk tables (floats)
+constexpr int R_TAB = W_FLOATS;                                // private tables start behind region W
+constexpr int R_FLOATS = (W_FLOATS + WAVES * E_TAB_FLOATS) > 2 * 36 * US ? (W_FLOATS + WAVES * E_TAB_FLOATS) : 2 * 36 * US;
 constexpr int OFF_R = OFF_Z1 + BLOCK_ENVS * 2 * 4 * 8;
 constexpr int OFF_ELIST = OFF_R + R_FLOATS * 4;                // uint16 eval list[128]
 constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[128] (5 action runs)
 constexpr int OFF_MAXQ = OFF_ULIST + BLOCK_ENVS * 2;           // float maxq[128] (per env)
-constexpr int OFF_DELTA = OFF_MAXQ + BLOCK_ENVS * 4;           // float delta[32] (per chunk slot)
-constexpr int OFF_ENV = OFF_DELTA + 32 * 4;                    // int env[128]: env index of each block slot
+constexpr int OFF_QSA = OFF_MAXQ + BLOCK_ENVS * 4;             // float qsa[128] (per update-list position)
+constexpr int OFF_ENV = OFF_QSA + BLOCK_ENVS * 4;              // int env[128]: env index of each block slot
 constexpr int OFF_CLF = OFF_ENV + BLOCK_ENVS * 4;              // float clf[6][8]
 constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[32]
 constexpr int LDS_BYTES = OFF_MISC + 128;
 static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
-static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0, "LDS alignment");
+static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0, "LDS alignment");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
@@ -194,12 +196,13 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
     uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
     float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
-    float *s_delta = reinterpret_cast<float *>(smem + OFF_DELTA);
+    float *s_qsa = reinterpret_cast<float *>(smem + OFF_QSA);
+    float *s_W = s_R;                                                   // region W = the head of region R
     int *s_env = reinterpret_cast<int *>(smem + OFF_ENV);
     float *s_clf = reinterpret_cast<float *>(smem + OFF_CLF);
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const int e0 = b * BLOCK_ENVS;
     const int nb = min(BLOCK_ENVS, A.n - e0);
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     }
 
     // ------------------------------------------------------------------ phase TD (SPEC §3.1, §5) on the matrix pipe
-    // Lane roles. As an MFMA operand lane (16x16x4): n = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
-    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of the
+    // Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
+    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
     // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
     // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
     // imaginary-part column at 8 h + 4 + i.
@@ -351,8 +354,24 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     const int bi = lane & 7, cp = lane >> 3;
     const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
     const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
-    const int ocol_part = (n16 >> 2) & 1;                     //               0 = re, 1 = im
     const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
+    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
+    const float *ab_lane = abq + n16 * 36 + 4 * g;
+
+    // private tables of one 8-item column block: items lst[i0 .. i0 + cnt) (a short block repeats its last item),
+    // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
+    auto build_block = [&](const uint16_t *lst, int i0, int cnt, int sg) {
+        if (cp < 6) {
+            const int it = lst[i0 + min(bi, cnt - 1)];
+            float2 ab[6], cd[6];
+            item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                abq[bcol * 36 + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * 36 + 6 * c + cp] = -ab[c].y;
+                cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
+            }
+        }
+    };
 
     const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[31]) : ~0u;
     for (int k = A.k_lo; k <= A.k_hi; ++k) {
@@ -383,6 +402,29 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 const uint64_t mine = lane == 0 ? mb[0] : lane == 1 ? mb[1] : lane == 2 ? mb[2] : lane == 3 ? mb[3]
                                                         : lane == 4 ? mb[4] : mb[5];
                 s_misc[wave * 8 + lane] = __popcll(mine);
+            }
+        }
+        // W_k -> LDS in A-operand order while the counts settle: W_k is a 180 x 36 matrix (row = 36 a + c12) cut into
+        // 12 row tiles; entry (tile t, k-block kb, lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 are zero.
+        // One coalesced read per workgroup instead of one 27 KB gather per wave (every workgroup of the chip reads
+        // the same 26 KB at the same moment: the L2 channels holding it were the bottleneck).
+        const float *Wk = A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF);
+        {
+            const float4 *Wk4 = reinterpret_cast<const float4 *>(Wk);
+            for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) {
+                const float4 w = Wk4[f4];
+                const int row = f4 / 9, c0 = 4 * (f4 - 9 * row);
+                const int base = ((row >> 4) * 9) * 64 + (row & 15);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e, gg = (c * 57) >> 9, kb = c - 9 * gg;      // c / 9, c % 9 for c < 36
+                    s_W[base + kb * 64 + gg * 16] = wv[e];
+                }
+            }
+            for (int z = tid; z < 9 * 4 * 12; z += THREADS) {                        // tile 11, rows 180..191
+                const int kb = z / 48, r = z - 48 * kb, gg = r / 12, nn = 4 + (r - 12 * gg);
+                s_W[(11 * 9 + kb) * 64 + gg * 16 + nn] = 0.0f;
             }
         }
         block_lds_sync();
@@ -421,251 +463,253 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
         block_lds_sync();
         if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = nupd;
-        SCG_STAMP(k == 0 ? 1 : 8);    // phase Z (first pass only) + list build
+        SCG_STAMP(k == 0 ? 1 : 8);    // phase Z (first pass only) + list build + W staging
         if (n_ev + nupd == 0) continue;
 
-        const float *Wk = A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF);
-        // ---- E: Q_k(s_next, .) of the eval list, one 8-item column block per wave-iteration (SPEC §3.1)
-        {
-            const int nqe = (n_ev + 7) >> 3;
-            if (wave < nqe) {
-                // A operands: W_k as a 180 x 36 matrix (row = 36 a + c12), 12 row tiles; lane (n16, g) holds, for tile t
-                // and k-block kb, W[16 t + n16][9 g + kb] — nine consecutive floats per tile (rows >= 180 are zero)
-                float Wr[12][9];
+        // column blocks of this pass: nqe of the eval list, then per action run ceil(run_len / 8) of the update list;
+        // block index i goes to wave i & 3
+        const int nqe = (n_ev + 7) >> 3;
+        int uq0[NACT + 1];
+        uq0[0] = nqe;
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) uq0[a + 1] = uq0[a] + ((run_len[a] + 7) >> 3);
+        if (wave < uq0[NACT]) {
+            float Wr[12][9];
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+#pragma unroll
+                for (int kb = 0; kb < 9; ++kb) Wr[t][kb] = s_W[(t * 9 + kb) * 64 + lane];
+            }
+            SCG_STAMP(k == 0 ? 2 : 9);    // A operands in registers
+            // ---- E: Q_k(s_next, .) of the eval list, one 8-item column block per wave-iteration (SPEC §3.1)
+            for (int cb = wave; cb < nqe; cb += WAVES) {
+                build_block(s_elist, 8 * cb, min(8, n_ev - 8 * cb), 1);
+                wave_lds_sync();
+                float B[9];
+#pragma unroll
+                for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+                f4v acc[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) acc[t] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int kb = 0; kb < 9; ++kb) {
+#pragma unroll
+                    for (int t = 0; t < 12; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[t][kb], B[kb], acc[t], 0, 0, 0);
+                }
+                // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
+                float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int t = 0; t < 12; ++t) {
-                    const int row = 16 * t + n16;
-                    const float *wp = Wk + (row < 180 ? row : 0) * 36 + 9 * g;
+                    const int Ct = (16 * t) % 36, At = (16 * t) / 36;
+                    if (Ct + 12 < 36) {                          // the tile's 16 rows belong to one action
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + Ct);
 #pragma unroll
-                    for (int kb = 0; kb < 9; ++kb) { const float v = wp[kb]; Wr[t][kb] = row < 180 ? v : 0.0f; }
+                        for (int v = 0; v < 4; ++v) q[At] = fmaf(acc[t][v], ab4[v], q[At]);
+                    } else {                                     // row groups g >= (36 - Ct) / 4 belong to the next action
+                        const bool wrap = 4 * g >= 36 - Ct;
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + (wrap ? Ct - 36 : Ct));
+                        float xq = wrap ? q[At + 1] : q[At];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) xq = fmaf(acc[t][v], ab4[v], xq);
+                        q[At] = wrap ? q[At] : xq;
+                        q[At + 1] = wrap ? xq : q[At + 1];
+                    }
                 }
-                SCG_STAMP(k == 0 ? 2 : 9);    // W fetch issued
-                float *cdk = s_R + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;
-                for (int cb = wave; cb < nqe; cb += WAVES) {
-                    // tables of the block's 8 items (a short last block repeats its last item)
-                    if (cp < 6) {
-                        const int it = s_elist[min(8 * cb + bi, n_ev - 1)];
-                        float2 ab[6], cd[6];
-                        item_entries(s_z1 + (it * 2 + 1) * 4, cp, ab, cd);
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            abq[bcol * 36 + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * 36 + 6 * c + cp] = -ab[c].y;
-                            cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
-                        }
-                    }
-                    wave_lds_sync();
-                    float B[9];
-#pragma unroll
-                    for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-                    f4v acc[12];
-#pragma unroll
-                    for (int t = 0; t < 12; ++t) acc[t] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int kb = 0; kb < 9; ++kb) {
-#pragma unroll
-                        for (int t = 0; t < 12; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[t][kb], B[kb], acc[t], 0, 0, 0);
-                    }
-                    // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
-                    float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int t = 0; t < 12; ++t) {
-                        const int Ct = (16 * t) % 36, At = (16 * t) / 36;
-                        const bool wrap = Ct + 4 * g >= 36;
-                        const int c0 = Ct + 4 * g - (wrap ? 36 : 0);
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + c0);
-                        if (Ct + 12 < 36) {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) q[At] = fmaf(acc[t][v], ab4[v], q[At]);
+                float qo[NACT] = {q[0], q[1], q[2], q[3], q[4]};
+                item_tree_sum<NACT>(qo);
+                if (out_lane && 8 * cb + ocol_item < n_ev) {
+                    const int il = s_elist[8 * cb + ocol_item];
+                    if (s_on[il] == k) {
+                        if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
+                            float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                            orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                            orec[3].x = qo[4];
                         } else {
-                            float xq = wrap ? q[At + 1] : q[At];
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) xq = fmaf(acc[t][v], ab4[v], xq);
-                            q[At] = wrap ? q[At] : xq;
-                            q[At + 1] = wrap ? xq : q[At + 1];
+                            for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
                         }
                     }
-                    float qo[NACT] = {q[0], q[1], q[2], q[3], q[4]};
-                    item_tree_sum<NACT>(qo);
-                    if (out_lane && 8 * cb + ocol_item < n_ev) {
-                        const int il = s_elist[8 * cb + ocol_item];
-                        if (s_on[il] == k) {
-                            if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
-                                float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
-                                orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
-                                orec[3].x = qo[4];
-                            } else {
+                    float mx = qo[0];
 #pragma unroll
-                                for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
-                            }
-                        }
-                        float mx = qo[0];
-#pragma unroll
-                        for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
-                        s_maxq[il] = mx;
-                    }
-                    wave_lds_sync();
+                    for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
+                    s_maxq[il] = mx;
                 }
+                wave_lds_sync();
+            }
+            SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
+            // ---- U1: Q_k(s, a_t) of the update items, per action run, 8 items per wave-iteration: the same contraction
+            // on the 3 row tiles that hold action a's rows -> s_qsa[list position]
+            if (MODE != MODE_QVAL && nupd > 0) {
+                auto run_u1 = [&](auto aa_c) {
+                    constexpr int AA = decltype(aa_c)::value;
+                    constexpr int T0 = (36 * AA) / 16;
+                    const int cnt = run_len[AA];
+                    const uint16_t *lst = s_ulist + run_off[AA];
+                    for (int cb = ((wave - uq0[AA]) & 3); 8 * cb < cnt; cb += WAVES) {
+                        build_block(lst, 8 * cb, min(8, cnt - 8 * cb), 0);
+                        wave_lds_sync();
+                        float B[9];
+#pragma unroll
+                        for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+                        f4v acc[3];
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) acc[tt] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int kb = 0; kb < 9; ++kb) {
+#pragma unroll
+                            for (int tt = 0; tt < 3; ++tt)
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[T0 + tt][kb], B[kb], acc[tt], 0, 0, 0);
+                        }
+                        float qs = 0.0f;
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) {
+                            constexpr int dummy_ = 0; (void)dummy_;
+                            const int r0 = 16 * (T0 + tt) + 4 * g - 36 * AA;       // c12 of the lane's first row, if in [0, 36)
+                            const bool in = r0 >= 0 && r0 < 36;
+                            const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + (in ? r0 : 0));
+                            float xq = qs;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) xq = fmaf(acc[tt][v], ab4[v], xq);
+                            qs = in ? xq : qs;
+                        }
+                        float qo[1] = {qs};
+                        item_tree_sum<1>(qo);
+                        if (out_lane && 8 * cb + ocol_item < cnt) s_qsa[run_off[AA] + 8 * cb + ocol_item] = qo[0];
+                        wave_lds_sync();
+                    }
+                };
+                run_u1(std::integral_constant<int, 0>{}); run_u1(std::integral_constant<int, 1>{});
+                run_u1(std::integral_constant<int, 2>{}); run_u1(std::integral_constant<int, 3>{});
+                run_u1(std::integral_constant<int, 4>{});
             }
         }
-        SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
         if (MODE == MODE_QVAL || nupd == 0) continue;
-        block_lds_sync();                                   // s_maxq crosses waves; region R changes hands
-        SCG_STAMP(k == 0 ? 4 : 11);   // wait for the other waves' E
+        SCG_STAMP(k == 0 ? 4 : 11);   // U1 (wave 0's share)
+        block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
+        SCG_STAMP(k == 0 ? 7 : 14);   // wait for the other waves
 
-        // ---- U: per action run, chunks of <= 32 update items (SPEC §5)
-        //   build  tables of the chunk's items (state s): CDT[c34][kap], ABq[kap][c12], kap = 2 j + part
-        //   U1     Q_k(s, a) of 8 items per wave on the 3 row tiles of action a -> delta -> PT[c12][kap] = delta * ABq
-        //   U2     G[a] += PT x CDT^T in groups of 4 items: one MFMA over the 4 real parts, one over the 4 imaginary
-        //          parts; the 9 output tiles of the action are dealt to the waves (tile q -> wave (q - a) & 3)
+        // ---- U2: the block partial (SPEC §5). Padded slots: every action run is padded with null items to a multiple of
+        // 4, run a occupying slots [off4[a], off4[a] + len4[a]). Chunks of 64 slots (128 K-steps, kap = 2 slot + part):
+        //   build  PT[c12][kap] = delta * ABsel, CDT[c34][kap] = CD  (null items: +0), all four waves
+        //   MFMA   G[a] += PT x CDT^T, groups of 4 items: one MFMA over their real parts, one over the imaginary parts;
+        //          the 9 output tiles of action a are dealt to the waves (tile q -> wave (q - a) & 3), accumulators stay in
+        //          registers for the whole pass and go straight to the block's slab
+        int off4[NACT + 1];
+        off4[0] = 0;
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) off4[a + 1] = off4[a] + ((run_len[a] + 3) & ~3);
+        int wave_u = wave;
+        asm volatile("" : "+s"(wave_u));                    // keeps the per-(wave, action) tile geometry inside the pass
         f4v accU[NACT][3];
 #pragma unroll
         for (int a = 0; a < NACT; ++a) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) accU[a][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
         }
-        float *cdt = s_R + U_CDT, *abqu = s_R + U_ABQ, *pt = s_R + U_PT;
-        auto run_u = [&](auto aa_c) {
-            constexpr int AA = decltype(aa_c)::value;
-            constexpr int T0 = (36 * AA) / 16;                       // first of the 3 row tiles holding action AA's rows
-            const int cnt = run_len[AA];
-            if (cnt == 0) return;
-            const uint16_t *lst = s_ulist + run_off[AA];
-            const int wq = (wave + AA) & 3;                          // this wave's U2 tiles: wq, wq + 4 (, 8 when wq == 0)
-            for (int c0 = 0; c0 < cnt; c0 += 32) {
-                const int len = min(32, cnt - c0), len4 = (len + 3) & ~3;
-                const bool mine = 8 * wave < len;                    // this wave has items in U1
-                // A operands of action AA's row tiles (L1/L2-resident; issued first so the build covers their latency)
-                float Wt[3][9];
-                if (mine) {
+        float *ptab = s_R, *ctab = s_R + 36 * US;
+        for (int ch0 = 0; ch0 < off4[NACT]; ch0 += 64) {
+            if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
+            // build: wave w, round r owns chunk slots 16 w + 8 r + bi
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) {
-                        const int row = 16 * (T0 + tt) + n16;
-                        const float *wp = Wk + (row < 180 ? row : 0) * 36 + 9 * g;
+            for (int r = 0; r < 2; ++r) {
+                const int slot = 16 * wave + 8 * r + bi, ps = ch0 + slot;
+                if (cp < 6 && ps < off4[NACT]) {
+                    int a_ = 0;
 #pragma unroll
-                        for (int kb = 0; kb < 9; ++kb) { const float v = wp[kb]; Wt[tt][kb] = row < 180 ? v : 0.0f; }
-                    }
-                }
-                // build: wave w owns chunk slots 8 w .. 8 w + 7
-                {
-                    const int j = 8 * wave + bi;
-                    if (cp < 6 && j < len4) {
-                        if (j < len) {
-                            const int it = lst[c0 + j];
-                            float2 ab[6], cd[6];
-                            item_entries(s_z1 + (it * 2 + 0) * 4, cp, ab, cd);
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                abqu[(2 * j) * 36 + 6 * c + cp] = ab[c].x; abqu[(2 * j + 1) * 36 + 6 * c + cp] = -ab[c].y;
-                                cdt[(6 * c + cp) * US + 2 * j] = cd[c].x; cdt[(6 * c + cp) * US + 2 * j + 1] = cd[c].y;
-                            }
-                        } else {                                     // null item padding the last group of 4
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) { cdt[(6 * c + cp) * US + 2 * j] = 0.0f; cdt[(6 * c + cp) * US + 2 * j + 1] = 0.0f; }
-                        }
-                    }
-                }
-                block_lds_sync();                                    // tables visible
-                if (mine) {
-                    const int kap = 2 * (8 * wave + ocol_item) + ocol_part;
-                    float B[9];
-#pragma unroll
-                    for (int kb = 0; kb < 9; ++kb) B[kb] = cdt[(9 * g + kb) * US + kap];
-                    f4v acc[3];
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) acc[tt] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int kb = 0; kb < 9; ++kb) {
-#pragma unroll
-                        for (int tt = 0; tt < 3; ++tt)
-                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wt[tt][kb], B[kb], acc[tt], 0, 0, 0);
-                    }
-                    float qs = 0.0f;
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) {
-                        const int r0 = 16 * (T0 + tt) + 4 * g - 36 * AA;       // c12 of the lane's first row, if in [0, 36)
-                        const bool in = r0 >= 0 && r0 < 36;
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(abqu + kap * 36 + (in ? r0 : 0));
-                        float xq = qs;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) xq = fmaf(acc[tt][v], ab4[v], xq);
-                        qs = in ? xq : qs;
-                    }
-                    float qo[1] = {qs};
-                    item_tree_sum<1>(qo);
-                    const int j = 8 * wave + ocol_item;
-                    if (out_lane && j < len) {
-                        const int il = lst[c0 + j];
-                        const float r = (k == 0) ? s_r0[il] : s_ro[il];
+                    for (int a = 1; a < NACT; ++a) a_ += ps >= off4[a] ? 1 : 0;
+                    const int o4 = a_ == 0 ? off4[0] : a_ == 1 ? off4[1] : a_ == 2 ? off4[2] : a_ == 3 ? off4[3] : off4[4];
+                    const int rl = a_ == 0 ? run_len[0] : a_ == 1 ? run_len[1] : a_ == 2 ? run_len[2] : a_ == 3 ? run_len[3] : run_len[4];
+                    const int ro = a_ == 0 ? run_off[0] : a_ == 1 ? run_off[1] : a_ == 2 ? run_off[2] : a_ == 3 ? run_off[3] : run_off[4];
+                    const int j = ps - o4;
+                    float *pd = ptab + cp * US + 2 * slot, *cdst = ctab + cp * US + 2 * slot;
+                    if (j < rl) {
+                        const int li = ro + j, il = s_ulist[li];
+                        const float rr = (k == 0) ? s_r0[il] : s_ro[il];
                         const float cont = (k == 0) ? s_c0[il] : s_co[il];
-                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], r) : r;
-                        s_delta[j] = target - qo[0];
-                    }
-                    wave_lds_sync();
-                    // PT[c12][kap] = delta_j * ABq[kap][c12] for this wave's 16 K-steps (null items: +0)
-                    {
-                        const int kp = 16 * wave + n16, jj = kp >> 1;
-                        const bool real = jj < len;
-                        const float d = real ? s_delta[jj] : 0.0f;
-                        if (jj < len4) {
+                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
+                        const float d = target - s_qsa[li];
+                        float2 ab[6], cd[6];
+                        item_entries(s_z1 + (il * 2 + 0) * 4, cp, ab, cd);
 #pragma unroll
-                            for (int m = 0; m < 9; ++m) {
-                                const int c12 = g + 4 * m;
-                                const float v = real ? abqu[kp * 36 + c12] : 0.0f;
-                                pt[c12 * US + kp] = d * v;
-                            }
+                        for (int c = 0; c < 6; ++c) {
+                            *reinterpret_cast<float2 *>(pd + 6 * c * US) = make_float2(d * ab[c].x, d * (-ab[c].y));
+                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(cd[c].x, cd[c].y);
+                        }
+                    } else {                                     // null item padding a run to a multiple of 4
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            *reinterpret_cast<float2 *>(pd + 6 * c * US) = make_float2(0.0f, 0.0f);
+                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(0.0f, 0.0f);
                         }
                     }
                 }
-                block_lds_sync();                                    // PT visible
-                {
-                    const int ngrp = len4 >> 2;
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        const int q = wq + 4 * s;
-                        if (s < 2 || wq == 0) {
-                            const int mi = (q * 11) >> 5, ni = q - 3 * mi;             // q / 3, q % 3 for q <= 8
-                            const float *pa = pt + min(16 * mi + n16, 35) * US + 2 * g;
-                            const float *pb = cdt + min(16 * ni + n16, 35) * US + 2 * g;
-                            for (int gi = 0; gi < ngrp; ++gi) {
-                                const float2 a2 = *reinterpret_cast<const float2 *>(pa + 8 * gi);
-                                const float2 b2 = *reinterpret_cast<const float2 *>(pb + 8 * gi);
-                                accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, accU[AA][s], 0, 0, 0);
-                                accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, accU[AA][s], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
-                block_lds_sync();                                    // chunk tables free again
             }
-        };
-        run_u(std::integral_constant<int, 0>{}); run_u(std::integral_constant<int, 1>{});
-        run_u(std::integral_constant<int, 2>{}); run_u(std::integral_constant<int, 3>{});
-        run_u(std::integral_constant<int, 4>{});
-        SCG_STAMP(k == 0 ? 6 : 13);   // U
-        // ---- the block partial P_b,k straight from the accumulators: tile (mi, ni) of action a, register v of lane
-        // (n16, g) = G[a][16 mi + 4 g + v][16 ni + n16]
+            block_lds_sync();                                    // operands visible
+            auto run_u2 = [&](auto aa_c) {
+                constexpr int AA = decltype(aa_c)::value;
+                const int lo = max(off4[AA], ch0), hi = min(off4[AA + 1], ch0 + 64);      // the run's slots in this chunk
+                if (lo >= hi) return;
+                const int wq = (wave_u + AA) & 3;                // this wave's tiles: wq, wq + 4 (, 8 when wq == 0)
+                const float *pa[3], *pb[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int q = min(wq + 4 * s, 8);
+                    const int mi = (q * 11) >> 5, ni = q - 3 * mi;             // q / 3, q % 3
+                    pa[s] = ptab + min(16 * mi + n16, 35) * US + 2 * g + 2 * (lo - ch0);
+                    pb[s] = ctab + min(16 * ni + n16, 35) * US + 2 * g + 2 * (lo - ch0);
+                }
+                const int ngrp = (hi - lo) >> 2;
+                if (wq == 0) {
+                    for (int gi = 0; gi < ngrp; ++gi) {
+                        float2 a2[3], b2[3];
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) { a2[s] = *reinterpret_cast<const float2 *>(pa[s] + 8 * gi); b2[s] = *reinterpret_cast<const float2 *>(pb[s] + 8 * gi); }
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].x, b2[s].x, accU[AA][s], 0, 0, 0);
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].y, b2[s].y, accU[AA][s], 0, 0, 0);
+                    }
+                } else {
+                    for (int gi = 0; gi < ngrp; ++gi) {
+                        float2 a2[2], b2[2];
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) { a2[s] = *reinterpret_cast<const float2 *>(pa[s] + 8 * gi); b2[s] = *reinterpret_cast<const float2 *>(pb[s] + 8 * gi); }
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].x, b2[s].x, accU[AA][s], 0, 0, 0);
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].y, b2[s].y, accU[AA][s], 0, 0, 0);
+                    }
+                }
+            };
+            run_u2(std::integral_constant<int, 0>{}); run_u2(std::integral_constant<int, 1>{});
+            run_u2(std::integral_constant<int, 2>{}); run_u2(std::integral_constant<int, 3>{});
+            run_u2(std::integral_constant<int, 4>{});
+        }
+        SCG_STAMP(k == 0 ? 6 : 13);   // U2
+        // the block partial P_b,k straight from the accumulators (zeros for an empty run):
+        // tile (mi, ni), register v of lane (n16, g) = G[a][16 mi + 4 g + v][16 ni + n16]
         {
-            float *slab = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF;
+            float *slab_lane = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF + (4 * g) * 36 + n16;
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
-                const int wq = (wave + a) & 3;
+                const int wq = (wave_u + a) & 3;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     const int q = wq + 4 * s;
                     if (s < 2 || wq == 0) {
-                        const int mi = (q * 11) >> 5, ni = q - 3 * mi;
-                        const int c34 = 16 * ni + n16;
+                        const int mi = (q * 11) >> 5, ni = q - 3 * mi;         // wave-uniform
+                        const bool okl = (mi < 2 || g == 0) && (ni < 2 || n16 < 4);
+                        float *dst = slab_lane + a * NF + (16 * mi) * 36 + 16 * ni;
+                        if (okl) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int c12 = 16 * mi + 4 * g + v;
-                            if (c12 < 36 && c34 < 36) gstore(&slab[a * NF + c12 * 36 + c34], accU[a][s][v]);
+                            for (int v = 0; v < 4; ++v) gstore(dst + v * 36, accU[a][s][v]);
                         }
                     }
                 }
             }
         }
-        SCG_STAMP(k == 0 ? 7 : 14);   // slab store
+        SCG_STAMP(15);                // slab stores issued
     }
 }
 

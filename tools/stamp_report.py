@@ -25,12 +25,13 @@ for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
 out = np.zeros((nblk, 16), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
-names = ["phase P", "root: phaseZ+lists", "root: W staging", "root: loop A", "root: wait A", "root: barrier at pass start", "root: loop C",
-         "root: reduce+slab", "opt: lists", "opt: W staging", "opt: loop A", "opt: wait A", "opt: barrier at pass start", "opt: loop C", "opt: reduce+slab", "-"]
+names = ["phase P", "root: phase Z + lists + W staging", "root: A operands -> registers", "root: E (eval)", "root: U1 (Q(s,a))",
+         "root: barrier at pass start", "root: U2 (accumulate)", "root: wait before U2", "opt: lists + W staging", "opt: A operands -> registers",
+         "opt: E (eval)", "opt: U1 (Q(s,a))", "opt: barrier at pass start", "opt: U2 (accumulate)", "opt: wait before U2", "slab stores"]
 mean = out.astype(np.float64).mean(0) / args.steps
 tot = mean.sum()
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
-for nme, v in zip(names, mean): print(f"  {nme:22s} {v:10.0f}  {100*v/tot:5.1f} %")
+for nme, v in zip(names, mean): print(f"  {nme:36s} {v:10.0f}  {100*v/tot:5.1f} %")
 per_block = out.astype(np.float64).sum(1) / args.steps
 print(f"per-block wave-0 total ticks per launch: min {per_block.min():.0f}  mean {per_block.mean():.0f}  max {per_block.max():.0f}"
       f"  (mean/max = {per_block.mean()/per_block.max():.2f}: one workgroup per CU, the launch lasts as long as its slowest)")
