@@ -54,7 +54,12 @@ constexpr int OFF_QSA = OFF_MAXQ + BLOCK_ENVS * 4;             // float qsa[128]
 constexpr int OFF_ENV = OFF_QSA + BLOCK_ENVS * 4;              // int env[128]: env index of each block slot
 constexpr int OFF_CLF = OFF_ENV + BLOCK_ENVS * 4;              // float clf[6][8]
 constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[32]
+#ifdef SCG_STAMPS
+constexpr int OFF_STAMP = OFF_MISC + 128;                      // unsigned stamp[32] (diagnostic build)
+constexpr int LDS_BYTES = OFF_STAMP + 128;
+#else
 constexpr int LDS_BYTES = OFF_MISC + 128;
+#endif
 static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
 static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0, "LDS alignment");
 
@@ -64,11 +69,12 @@ enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 // workgroup accumulates s_memtime deltas per kernel section into A.stamps[block][section]. The shipped
 // library is built without SCG_STAMPS and contains none of this.
 #ifdef SCG_STAMPS
+
 #define SCG_STAMP(SEC)                                                                   \
     do {                                                                                 \
         if (MODE == MODE_FUSED && A.stamps && tid == 0) {                                \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
-            A.stamps[(size_t)blockIdx.x * 16 + (SEC)] += t_ - stamp_prev;                \
+            s_stamp[(SEC)] += (unsigned)(t_ - stamp_prev);                               \
             stamp_prev = t_;                                                             \
         }                                                                                \
     } while (0)
@@ -208,6 +214,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     const int nb = min(BLOCK_ENVS, A.n - e0);
     const int N = A.n;
 #ifdef SCG_STAMPS
+    unsigned *s_stamp = reinterpret_cast<unsigned *>(smem + OFF_STAMP);
+    if (tid < 32) s_stamp[tid] = 0;
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -219,8 +227,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     }
 
     // ------------------------------------------------------------------ phase P
-    if (lane < 32) {                                  // 4 waves x 32 lanes
-        const int i = wave * 32 + lane;
+    if (lane < 32) {                                  // 4 waves x 32 lanes (64-lane waves measured slower: 22.1k vs 18.8k
+        const int i = wave * 32 + lane;               // cycles for the physics — more divergence per wave)
         const int e = (MODE == MODE_FUSED && A.perm && i < nb) ? A.perm[e0 + i] : e0 + i;
         s_env[i] = e;
         if (i < nb) {
@@ -240,13 +248,16 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     if (q > best) { best = q; a_greedy = a; }
                 }
                 const int a = explore ? a_rand : a_greedy;
+                SCG_STAMP(16);                                        // P: perm + qcache gathers, Philox, action
                 float sx = A.x[e], sy = A.y[e], svx = A.vx[e], svy = A.vy[e];
                 const int ep0 = A.ep_steps[e], o = A.option_id[e], osteps = A.opt_steps[e];   // early: latency hides under the physics
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
                 // physics (SPEC §1.3)
                 bool goal;
+                SCG_STAMP(17);                                        // P: state gathers
                 const float rew = pinball_step_any(s_edges, A.cellmask, A.ms, sx, sy, svx, svy, a, goal);
+                SCG_STAMP(18);                                        // P: physics
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = ep0 + 1;
                 const bool timeout = !goal && eps1 >= A.max_ep;
@@ -303,6 +314,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
                                           __int_as_float(osn), __int_as_float(epn));
                 }
+                SCG_STAMP(19);                                        // P: bookkeeping, option logic, result line
                 if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
                     const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
                     A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
@@ -711,6 +723,12 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(15);                // slab stores issued
     }
+#ifdef SCG_STAMPS
+    if (MODE == MODE_FUSED && A.stamps) {
+        __syncthreads();
+        if (tid < 32) A.stamps[(size_t)blockIdx.x * 32 + tid] += s_stamp[tid];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1336,8 +1354,8 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         return st;
     }
 #ifdef SCG_STAMPS
-    if (hipMalloc(&c->d_stamps, (size_t)c->nblk * 16 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 16 * sizeof(unsigned long long));
+    if (hipMalloc(&c->d_stamps, (size_t)c->nblk * 32 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 32 * sizeof(unsigned long long));
 #endif
     c->parents = 0;
     for (int k = 1; k < MAX_VF; ++k) c->parents |= (uint32_t)(k - 1) << (3 * k);      // chain: 1 -> goal, k -> k-1
@@ -1529,8 +1547,8 @@ int scg_invalidate_order(scg_ctx *c) {
 #ifdef SCG_STAMPS
 extern "C" int scg_diag_stamps(scg_ctx *c, unsigned long long *host_out /*[nblk][16]*/, int32_t reset) {
     if (!c || !c->d_stamps) return SCG_ERR_STATE;
-    if (host_out && hipMemcpy(host_out, c->d_stamps, (size_t)c->nblk * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return SCG_ERR_HIP;
-    if (reset) (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 16 * sizeof(unsigned long long));
+    if (host_out && hipMemcpy(host_out, c->d_stamps, (size_t)c->nblk * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return SCG_ERR_HIP;
+    if (reset) (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 32 * sizeof(unsigned long long));
     return SCG_OK;
 }
 #endif

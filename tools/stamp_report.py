@@ -23,11 +23,12 @@ nblk = n // lib.scg_block_envs()
 lib.scg_diag_stamps(ctx, None, 1)
 for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
-out = np.zeros((nblk, 16), np.uint64)
+out = np.zeros((nblk, 32), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
-names = ["phase P", "root: phase Z + lists + W staging", "root: A operands -> registers", "root: E (eval)", "root: U1 (Q(s,a))",
+names = ["phase P (rest: trace, hist, barrier)", "root: phase Z + lists + W staging", "root: A operands -> registers", "root: E (eval)", "root: U1 (Q(s,a))",
          "root: barrier at pass start", "root: U2 (accumulate)", "root: wait before U2", "opt: lists + W staging", "opt: A operands -> registers",
-         "opt: E (eval)", "opt: U1 (Q(s,a))", "opt: barrier at pass start", "opt: U2 (accumulate)", "opt: wait before U2", "slab stores"]
+         "opt: E (eval)", "opt: U1 (Q(s,a))", "opt: barrier at pass start", "opt: U2 (accumulate)", "opt: wait before U2", "slab stores",
+         "P: perm, qcache, Philox, action", "P: state gathers", "P: physics", "P: bookkeeping, options, result line"] + ["-"] * 12
 mean = out.astype(np.float64).mean(0) / args.steps
 tot = mean.sum()
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
