@@ -622,6 +622,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         float *ptab = s_R, *ctab = s_R + 36 * US;
         for (int ch0 = 0; ch0 < off4[NACT]; ch0 += 64) {
             if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
+            SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
             // build: wave w, round r owns chunk slots 16 w + 8 r + bi
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -657,7 +658,9 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     }
                 }
             }
+            SCG_STAMP(21);                                       // (diagnostic) U2: build
             block_lds_sync();                                    // operands visible
+            SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
             auto run_u2 = [&](auto aa_c) {
                 constexpr int AA = decltype(aa_c)::value;
                 const int lo = max(off4[AA], ch0), hi = min(off4[AA + 1], ch0 + 64);      // the run's slots in this chunk
