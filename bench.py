@@ -6,7 +6,7 @@ Q + TD + weight update) over this rank's env shard, inputs resident in HBM. Work
 configs[2]/[3]: 65 536 envs per GPU, full skill chain (5 options), independent env shards, no
 collective ("scaling": "weak"); --shared-weights switches to configs[4] (RCCL all-reduce of dW).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line. `roofline` prices the dominant kernel (td_kernel<FUSED>) from HIP events
@@ -28,7 +28,7 @@ ENVS_PER_GPU = 65536
 N_OPTIONS = 5
 MAP = "pinball_simple"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 vector
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32-input MFMA peak (= the FP32 vector peak)
 BYTES_PER_ENV_STEP = 46         # SURVEY.md §8(d) algorithmic HBM bytes per env-step
 HP = dict(gamma=0.99, alpha=1e-3, epsilon=0.05, r_option_success=100.0, max_episode_steps=2000,
           max_option_steps=250)
@@ -87,12 +87,12 @@ def cpu_baseline(seconds_target=15.0):
     import sc_oracle
     import skill_chaining_with_graphs_amd as scg
     from skill_chaining_with_graphs_amd.core import fourier_scale_table
-    cores = min(os.cpu_count() or 1, 16)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     m = scg.load_map(MAP)
     clf = chain_discs(m, N_OPTIONS)
 
     def timed(threads, budget):
-        n = 256 * threads                     # one 256-env block per thread
+        n = 128 * threads                     # one 128-env block (SPEC §5) per thread
         orc = sc_oracle.Oracle(m, fourier_scale_table(), n_envs=n, n_options=N_OPTIONS, seed=0,
                                enabled_mask=sum(1 << k for k in range(1, N_OPTIONS + 1)), n_threads=threads, **HP)
         st = sc_oracle.new_state(n, m)
@@ -116,7 +116,8 @@ def cpu_baseline(seconds_target=15.0):
     v1, n1, s1, d1 = timed(1, seconds_target / 3.0)
     vc, nc, sc, dc = timed(cores, seconds_target * 2.0 / 3.0)
     return {"value": vc, "unit": "env-steps/s", "cores": cores, "kind": "port", "single_thread_value": v1,
-            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, OpenMP over 256-env blocks), same workload: "
+            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, scalar fmaf chains, OpenMP over 128-env blocks; `cores` = "
+                      f"every core this process may run on), same workload: "
                       f"{nc} envs x {sc} step-batches on {cores} threads in {dc:.1f} s; {n1} envs x {s1} step-batches "
                       f"on 1 thread in {d1:.1f} s; the upstream reference ships no code to time"}
 
@@ -136,8 +137,28 @@ def main():
     ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
     ap.add_argument("--diag-fresh-sort", action="store_true", help="diagnostic: stand-alone sort kernels every step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--event-every", type=int, default=8, help="HIP event pair round every n-th fused-kernel launch")
+    ap.add_argument("--event-every", type=int, default=0, help="HIP event pair round every n-th fused-kernel launch "
+                    "(0 = max(2, steps // 8): each pair costs a few us of queue bubble, so at most every other launch is sampled)")
+    ap.add_argument("--ramp", type=int, default=200, help="untimed clock-ramp step-batches before the warm-up "
+                    "(a 20-step run otherwise times a cold GPU and the first step's stand-alone sort)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: become the launcher. Nothing in this process has touched the GPU (no torch
+        # import yet): start N fresh rank processes through torch.distributed.run and relay rank 0's JSON line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if lines:
+            print(lines[-1], flush=True)
+        sys.exit(r.returncode if r.returncode else (0 if lines else 1))
 
     import numpy as np
     import torch
@@ -148,10 +169,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     rehearsal = args.backend == "gloo"
     if rehearsal:
         local_rank = 0                      # all ranks share the one card; gloo carries the (tiny) collectives
@@ -195,10 +213,13 @@ def main():
                             agent.ctx._stream())
             agent.t += 1
         agent.step_batch = _step
+    for _ in range(args.ramp):                    # untimed, not counted as warm-up: clocks up, env order prepared
+        agent.step_batch(learn)
     for _ in range(args.warmup):
         agent.step_batch(learn)
     barrier()
-    lib.scg_profile_reset(ctx, args.event_every)  # HIP events round the fused kernel, on the launch stream
+    event_every = args.event_every if args.event_every > 0 else max(2, args.steps // 8)
+    lib.scg_profile_reset(ctx, event_every)       # HIP events round the fused kernel, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.step_batch(learn)
@@ -224,7 +245,7 @@ def main():
         out = {
             "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt_max / args.steps * 1e3, "untimed_ramp_steps": args.ramp, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_local} envs/GPU x {world} GPU, map {MAP}, Fourier order 5 (1296 terms), "
                                    f"root + {n_opt} chained options (synthetic nested-disc initiation sets), "
@@ -234,19 +255,22 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(n_local, n_opt), "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                         "note": "the fused kernel is fp32-VALU-bound, not HBM-bound (SURVEY.md §8d, DESIGN.md): "
-                                 "see `valu` for the binding roofline"},
+                         "note": "the fused kernel is bound by the f32 matrix pipe, not by HBM (SURVEY.md \u00a78d, DESIGN.md): "
+                                 "see `mfma` for the binding roofline"},
         }
-        # the binding (VALU) roofline: algorithmic flops of the TD items this rank processed per step
+        # the binding (matrix-pipe) roofline: algorithmic flops of the TD items this rank processed per step
         st = agent.state
         opt = st.option_id.cpu().numpy()
         n_opt_items = int((opt > 0).sum())
         flops_step = units * flops_per_item(True, True) + n_opt_items * flops_per_item(True, True)
-        out["valu"] = {"bound": "valu_fp32", "achieved": flops_step / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
-                       "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": (flops_step / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS) if kern_ms > 0 else 0.0,
+        out["mfma"] = {"bound": "mfma", "dtype": "f32", "achieved": flops_step / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0,
+                       "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": (flops_step / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if kern_ms > 0 else 0.0,
                        "algorithmic_flop_per_step_batch": flops_step,
-                       "envs_in_an_option_at_end": n_opt_items}
+                       "envs_in_an_option_at_end": n_opt_items,
+                       "note": "algorithmic flops of the direct formulation (phi, Q, accumulate: DESIGN.md) over the "
+                               "dense f32 MFMA peak (= the f32 vector peak, MI355X_MICROARCH.md); the kernel runs the "
+                               "contractions in factorised form on v_mfma_f32_16x16x4_f32 and issues ~1.9x these flops"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:

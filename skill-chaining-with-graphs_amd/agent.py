@@ -10,6 +10,7 @@ from typing import List, Optional
 
 import torch
 
+from . import dist as _dist
 from ._lib import CLF_STRIDE, NUM_ACTIONS, NUM_FEATURES
 from .core import EnvState, ScgContext
 from .maps import PinballMap, load_map
@@ -67,12 +68,18 @@ class SkillChainingAgent:
             xy, lab = xy.view(-1, 2)[keep], lab.view(-1)[keep]
             px, pl = self._examples.get(k, (xy[:0], lab[:0]))
             self._examples[k] = (torch.cat([px, xy]), torch.cat([pl, lab]))
-        return int(self._examples.get(k, (torch.empty(0),))[0].shape[0])
+        got = int(self._examples.get(k, (torch.empty(0),))[0].shape[0])
+        if self.group is not None:           # sharded agent: every rank sees the node-wide count, so that the outer
+            got = _dist.allreduce_sum_int(got, self.group, self.W.device)      # loop takes the same branch everywhere
+        return got
 
     def create_option(self, k: int, iters: int = 400, lr: float = 3.0, l2: float = 1e-4) -> float:
         """Fit initiation classifier k on the collected examples (GPU logistic regression), start its value
         function from the root's, enable it. Returns the training accuracy."""
-        xy, lab = self._examples[k]
+        xy, lab = self._examples.get(k, (torch.zeros((0, 2), dtype=torch.float32, device=self.W.device),
+                                          torch.zeros((0,), dtype=torch.uint8, device=self.W.device)))
+        if self.group is not None:           # fit on the examples of ALL ranks (rank order): identical classifiers everywhere
+            xy, lab = _dist.allgather_rows(xy.contiguous(), self.group), _dist.allgather_rows(lab.contiguous(), self.group)
         clf = self.options[k].initiation_classifier
         clf.fit(xy.contiguous(), lab.contiguous(), iters=iters, lr=lr, l2=l2)
         self.W[k].copy_(self.W[0])
@@ -138,13 +145,7 @@ class SkillChainingAgent:
             gp = self.ctx.grad_packed()                  # G and the update counts: ONE all-reduce operand
         self.ctx.step(self.state, self.W, self.clf, self.enabled_mask, self.t, learn=learn, apply=not shared)
         if shared:
-            import torch.distributed as dist
-            if dist.get_backend(self.group) == "gloo":  # CPU rehearsal of the N>1 path: stage through the host
-                gc = gp.cpu()
-                dist.all_reduce(gc, group=self.group)
-                gp.copy_(gc)
-            else:
-                dist.all_reduce(gp, group=self.group)   # RCCL over xGMI: one latency-bound 26 KB x n_vf message
+            _dist.allreduce_packed(gp, self.group)      # RCCL over xGMI: one latency-bound 26 KB x n_vf message
             self.ctx.apply_update_packed(self.W, gp)
         self.t += 1
 

@@ -1283,6 +1283,28 @@ static int fail(scg_ctx *ctx, int code, const char *msg) {
     return code;
 }
 
+// Every entry point that touches the device runs with the ctx's device current and leaves the caller's current
+// device as it found it (a multi-GPU caller that forgot torch.cuda.set_device would otherwise launch on the
+// wrong card, against buffers owned by another GPU).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { ok = false; return; }
+        if (cur != dev) {
+            if (hipSetDevice(dev) != hipSuccess) { ok = false; return; }
+            prev = cur;
+        }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define SCG_ON_DEVICE(c, what)                                                                   \
+    DeviceGuard dev_guard_((c)->cfg.device);                                                     \
+    if (!dev_guard_.ok) return fail((c), SCG_ERR_HIP, what ": cannot make the context's device current")
+
 extern "C" {
 
 int scg_abi_version(void) { return SCG_ABI_VERSION; }
@@ -1322,8 +1344,9 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
     c->n_vf = cfg->n_options + 1;
     c->nblk = (cfg->n_envs + BLOCK_ENVS - 1) / BLOCK_ENVS;
     int st = SCG_OK;
+    DeviceGuard dev_guard_(cfg->device);
     do {
-        if (hipSetDevice(cfg->device) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (!dev_guard_.ok) { st = SCG_ERR_HIP; break; }
         const size_t slab_bytes = (size_t)c->nblk * c->n_vf * NACT * NF * sizeof(float);
         if (hipMalloc(&c->d_slabs, slab_bytes) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_cnts, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
@@ -1395,7 +1418,7 @@ int scg_set_map(scg_ctx *c, const float *edges, int32_t n_edges, const float *st
     if (!edges || !starts || !map_scalars || !scale) return fail(c, SCG_ERR_INVALID, "scg_set_map: null argument");
     if (n_edges < 0 || n_edges > MAX_EDGES) return fail(c, SCG_ERR_INVALID, "scg_set_map: n_edges out of range [0,256]");
     if (n_starts < 1) return fail(c, SCG_ERR_INVALID, "scg_set_map: need at least one start position");
-    SCG_HIP(c, hipSetDevice(c->cfg.device));
+    SCG_ON_DEVICE(c, "scg_set_map");
     if (c->d_starts) { (void)hipFree(c->d_starts); c->d_starts = nullptr; }
     SCG_HIP(c, hipMalloc(&c->d_starts, (size_t)n_starts * 2 * sizeof(float)));
     if (n_edges > 0) SCG_HIP(c, hipMemcpy(c->d_edges, edges, (size_t)n_edges * 8 * sizeof(float), hipMemcpyHostToDevice));
@@ -1484,6 +1507,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     if (!x || !y || !vx || !vy || !option_id || !opt_steps || !ep_steps || !qcache || !action || !reward ||
         !done || !W || !clf)
         return fail(c, SCG_ERR_INVALID, "scg_step: null array argument");
+    SCG_ON_DEVICE(c, "scg_step");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     StepArgs A;
     fill_common(c, A);
@@ -1590,6 +1614,7 @@ int scg_harvest(scg_ctx *c, int32_t n_sel, const int32_t *sel_env, const float *
     if (n_sel < 0 || l_pos < 0 || l_neg < 0 || l_pos + l_neg < 1 || ring_len < 1 || (ring_len & (ring_len - 1)) ||
         !sel_env || !ring_x || !ring_y || !ev_len || !out_xy || !out_label)
         return fail(c, SCG_ERR_INVALID, "scg_harvest: bad argument");
+    SCG_ON_DEVICE(c, "scg_harvest");
     if (n_sel == 0) return SCG_OK;
     const long long total = (long long)n_sel * (l_pos + l_neg);
     hipLaunchKernelGGL(harvest_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -1649,6 +1674,7 @@ int scg_set_grad_buffer_packed(scg_ctx *c, float *G_packed) {
 int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *stream) {
     if (!c || !W || !G_packed) return fail(c, SCG_ERR_INVALID, "scg_apply_update_packed: null argument");
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update_packed: scg_set_map has not been called (scale table)");
+    SCG_ON_DEVICE(c, "scg_apply_update_packed");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G_packed,
                        (const int32_t *)nullptr, G_packed + (size_t)c->n_vf * NACT * NF, c->d_scale, c->cfg.alpha);
@@ -1659,6 +1685,7 @@ int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *s
 int scg_apply_update(scg_ctx *c, float *W, const float *G, const int32_t *n_k, void *stream) {
     if (!c || !W || !G || !n_k) return fail(c, SCG_ERR_INVALID, "scg_apply_update: null argument");
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update: scg_set_map has not been called (scale table)");
+    SCG_ON_DEVICE(c, "scg_apply_update");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G, n_k,
                        (const float *)nullptr, c->d_scale, c->cfg.alpha);
@@ -1672,6 +1699,7 @@ int scg_pinball_step(scg_ctx *c, int32_t n, float *x, float *y, float *vx, float
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_pinball_step: scg_set_map has not been called");
     if (n < 0 || !x || !y || !vx || !vy || !action || !reward || !goal)
         return fail(c, SCG_ERR_INVALID, "scg_pinball_step: bad argument");
+    SCG_ON_DEVICE(c, "scg_pinball_step");
     if (n == 0) return SCG_OK;
     hipLaunchKernelGGL(pinball_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        n, x, y, vx, vy, action, reward, goal, c->d_edges, c->d_cellmask, c->ms);
@@ -1683,6 +1711,7 @@ int scg_fourier_features(scg_ctx *c, int32_t n, const float *x, const float *y, 
                          const float *vy, float *phi, void *stream) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_fourier_features: null ctx");
     if (n < 0 || !x || !y || !vx || !vy || !phi) return fail(c, SCG_ERR_INVALID, "scg_fourier_features: bad argument");
+    SCG_ON_DEVICE(c, "scg_fourier_features");
     if (n == 0) return SCG_OK;
     const int grid = n < 8192 ? n : 8192;
     hipLaunchKernelGGL(features_kernel, dim3(grid), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), n, x, y,
@@ -1695,6 +1724,7 @@ int scg_q_values(scg_ctx *c, int32_t n, const float *x, const float *y, const fl
                  const float *Wk, float *q, void *stream) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_q_values: null ctx");
     if (n < 0 || !x || !y || !vx || !vy || !Wk || !q) return fail(c, SCG_ERR_INVALID, "scg_q_values: bad argument");
+    SCG_ON_DEVICE(c, "scg_q_values");
     if (n == 0) return SCG_OK;
     StepArgs A;
     fill_common(c, A);
@@ -1716,6 +1746,7 @@ int scg_q_update(scg_ctx *c, int32_t n, int32_t k, const float *x, const float *
     if (k < 0 || k >= c->n_vf) return fail(c, SCG_ERR_INVALID, "scg_q_update: VF index out of range");
     if (!x || !y || !vx || !vy || !action || !r || !cont || !xn || !yn || !vxn || !vyn || !W)
         return fail(c, SCG_ERR_INVALID, "scg_q_update: null array argument");
+    SCG_ON_DEVICE(c, "scg_q_update");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblk = (n + BLOCK_ENVS - 1) / BLOCK_ENVS;
     SCG_HIP(c, hipMemsetAsync(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t), s));
@@ -1737,6 +1768,7 @@ int scg_classifier_predict(scg_ctx *c, int32_t n, const float *x, const float *y
                            void *stream) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_classifier_predict: null ctx");
     if (n < 0 || !x || !y || !w8 || !out) return fail(c, SCG_ERR_INVALID, "scg_classifier_predict: bad argument");
+    SCG_ON_DEVICE(c, "scg_classifier_predict");
     if (n == 0) return SCG_OK;
     hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        n, x, y, w8, out);
@@ -1749,6 +1781,7 @@ int scg_fit_initiation(scg_ctx *c, int32_t n_fit, const float *xy, const uint8_t
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_fit_initiation: null ctx");
     if (n_fit < 0 || iters < 0 || !xy || !label || !offsets || !w)
         return fail(c, SCG_ERR_INVALID, "scg_fit_initiation: bad argument");
+    SCG_ON_DEVICE(c, "scg_fit_initiation");
     if (n_fit == 0 || iters == 0) return SCG_OK;
     hipLaunchKernelGGL(fit_kernel, dim3(n_fit), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), xy, label,
                        offsets, w, iters, lr, l2);
