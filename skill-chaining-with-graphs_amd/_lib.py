@@ -14,8 +14,6 @@ NUM_FEATURES = 1296
 MAX_OPTIONS = 5
 MAX_EDGES = 256
 CLF_STRIDE = 8
-BLOCK_ENVS = 256
-WAVES = 8
 
 STEP_LEARN = 1
 STEP_APPLY = 2
@@ -96,6 +94,11 @@ def load() -> C.CDLL:
         raise ScgError("libscg_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def block_envs() -> int:
+    """SPEC §5 block size of the loaded library (envs whose update items share one accumulation chain)."""
+    return int(load().scg_block_envs())
 
 
 def check(status: int, ctx=None, what: str = "") -> None:

@@ -76,14 +76,22 @@ class Option:
             return torch.zeros_like(x, dtype=torch.uint8)
         return self.initiation_classifier.predict(x, y)
 
-    def beta(self, x: torch.Tensor, y: torch.Tensor, goal: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Termination indicator at post-step positions (SPEC §4.2 without the time-out terms): reached the
-        target region, or left the initiation set. `goal` = the env's goal flags (needed for k <= 1)."""
+    def beta(self, x: torch.Tensor, y: torch.Tensor, goal: Optional[torch.Tensor] = None,
+             done: Optional[torch.Tensor] = None, opt_steps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Termination indicator of SPEC §4.2 at post-physics positions (x, y) = s':
+        term = (done != 0) | succ | fail | otime, with succ = goal (parent 0) or in_parent(s'), fail = !succ & !in_k(s'),
+        otime = opt_steps + 1 >= max_option_steps. `goal` = the step's goal flags (needed when the option, or k = 0,
+        targets the task goal); `done` = the step's done codes (time-limit truncation also terminates); `opt_steps` = the
+        option's step counters BEFORE the step. Omitted inputs count as "did not happen". The classifier tests run on
+        the GPU (scg_classifier_predict); the rest is mask logic on their uint8 outputs, exactly as in the fused step."""
         ag, k = self.agent, self.index
-        g = goal.bool() if goal is not None else torch.zeros_like(x, dtype=torch.bool)
+        z = torch.zeros_like(x, dtype=torch.bool)
+        g = goal.bool() if goal is not None else z
+        d = (done != 0) if done is not None else z
         if k == 0:
-            return g.to(torch.uint8)
+            return (g | d).to(torch.uint8)
         parent = int(ag.ctx.parents[k])               # SPEC §4.2 skill graph (default chain: k - 1)
         succ = g if parent == 0 else ag.options[parent].in_initiation_set(x, y).bool()
         fail = ~succ & ~self.in_initiation_set(x, y).bool()
-        return (g | succ | fail).to(torch.uint8)
+        otime = (opt_steps + 1 >= int(ag.ctx.cfg.max_option_steps)) if opt_steps is not None else z
+        return (d | succ | fail | otime).to(torch.uint8)

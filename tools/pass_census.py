@@ -1,5 +1,5 @@
-import sys, numpy as np, torch
-sys.path[:0]=['/root/repo']
+import os, sys, numpy as np, torch
+sys.path[:0]=[os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import bench
 from skill_chaining_with_graphs_amd import SkillChainingAgent
 n=65536; nopt=5
