@@ -1,0 +1,67 @@
+"""CPU-side sanitizer runs (GPU sanitizers are not available on the pool):
+ * the oracle built with AddressSanitizer + UBSan over the oracle-level tests (`make -C oracle asan-test`);
+ * libscg_hip.so with its HOST half instrumented by ASan + UBSan: every C-ABI entry point's argument checks and error
+   paths, driven without a GPU."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_under_asan_ubsan():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan-test"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+_DRIVER = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import skill_chaining_with_graphs_amd as scg
+from skill_chaining_with_graphs_amd._lib import ScgConfig
+lib = scg.load_library()
+assert scg.LIB_PATH.endswith("libscg_hip_hostasan.so")
+assert lib.scg_abi_version() == 1 and lib.scg_block_envs() == 128
+assert lib.scg_strerror(0) == b"ok" and lib.scg_strerror(-4).startswith(b"call order") and lib.scg_strerror(77) == b"unknown status"
+ctx = C.c_void_p()
+bad = [dict(n_envs=0), dict(n_options=9), dict(fourier_order=3), dict(device=-1)]
+for kw in bad:
+    cfg = ScgConfig(n_envs=64, n_options=1, fourier_order=5, device=0)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    rc = lib.scg_create(C.byref(ctx), C.byref(cfg))
+    assert rc < 0 and not ctx.value, (kw, rc)
+    assert len(lib.scg_last_error(None)) > 0
+assert lib.scg_create(None, None) == -1
+good = ScgConfig(n_envs=64, n_options=1, fourier_order=5, device=0)
+rc = lib.scg_create(C.byref(ctx), C.byref(good))
+if rc != 0:                                    # no GPU here: the no-device path
+    assert rc in (-2, -3) and not ctx.value
+    null = C.c_void_p()
+    z = [None] * 13
+    assert lib.scg_step(null, *z, 0, 0, 0, None) == -1
+    assert lib.scg_set_map(null, None, 0, None, 0, None, None) == -1
+    assert lib.scg_q_update(null, 0, 0, *[None] * 12, 0, None) == -1
+    assert lib.scg_q_values(null, 0, *[None] * 6, None) == -1
+    assert lib.scg_fit_initiation(null, 0, None, None, None, None, 0, C.c_float(0), C.c_float(0), None) == -1
+    assert lib.scg_harvest(null, 0, None, None, None, 0, None, 0, 0, None, None, None) == -1
+    assert lib.scg_set_option_parents(null, None) == -1 and lib.scg_invalidate_order(null) == -1
+    assert lib.scg_profile_reset(null, 0) == -1 and lib.scg_destroy(null) == 0
+else:
+    lib.scg_destroy(ctx)
+print("host-asan ok")
+"""
+
+
+def test_c_abi_host_paths_under_asan_ubsan():
+    csrc = os.path.join(ROOT, "skill-chaining-with-graphs_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "hostasan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"],
+                        capture_output=True, text=True).stdout.strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               SCG_LIB=os.path.join(csrc, "libscg_hip_hostasan.so"))
+    r = subprocess.run([sys.executable, "-c", _DRIVER % {"root": ROOT}], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "host-asan ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
