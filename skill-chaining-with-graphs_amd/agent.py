@@ -149,6 +149,48 @@ class SkillChainingAgent:
             self.ctx.apply_update_packed(self.W, gp)
         self.t += 1
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    _STATE_FIELDS = ("x", "y", "vx", "vy", "option_id", "opt_steps", "ep_steps", "qcache", "action", "reward", "done")
+
+    def state_dict(self) -> dict:
+        """Everything a bit-identical continuation needs: the env SoA, W, the classifier table, the option graph, the
+        enabled mask, the step counter (RNG streams are keyed by (seed, global env id, t): no RNG state to save) and,
+        when tracing, the trajectory ring + events + the examples collected so far. Tensors are copied to the host."""
+        d = {"format": 1, "n_envs": self.n_envs, "n_options": self.n_options, "t": int(self.t),
+             "enabled_mask": int(self.enabled_mask), "parents": torch.as_tensor(self.ctx.parents.copy()),
+             "W": self.W.cpu(), "clf": self.clf.cpu(),
+             "state": {f: getattr(self.state, f).cpu() for f in self._STATE_FIELDS}}
+        if getattr(self, "trace", None) is not None:
+            ring_x, ring_y, events, ev_len = self.trace
+            d["trace"] = {"ring_x": ring_x.cpu(), "ring_y": ring_y.cpu(), "events": events.cpu(), "ev_len": ev_len.cpu()}
+            d["examples"] = {int(k): (xy.cpu(), lab.cpu()) for k, (xy, lab) in self._examples.items()}
+            d["prev_in"] = {int(k): v.cpu() for k, v in self._prev_in.items()}
+        return d
+
+    def load_state_dict(self, d: dict) -> None:
+        if d.get("format") != 1 or d["n_envs"] != self.n_envs or d["n_options"] != self.n_options:
+            raise ValueError("checkpoint does not match this agent (format / n_envs / n_options)")
+        dev = self.W.device
+        self.W.copy_(d["W"]); self.clf.copy_(d["clf"])
+        for f in self._STATE_FIELDS:
+            getattr(self.state, f).copy_(d["state"][f])
+        self.t, self.enabled_mask = int(d["t"]), int(d["enabled_mask"])
+        if self.n_options:
+            self.ctx.set_option_parents([int(v) for v in d["parents"]])
+        if "trace" in d:
+            self.enable_tracing(int(d["trace"]["ring_x"].shape[0]))
+            for name, buf in zip(("ring_x", "ring_y", "events", "ev_len"), self.trace):
+                buf.copy_(d["trace"][name])
+            self._examples = {int(k): (xy.to(dev), lab.to(dev)) for k, (xy, lab) in d["examples"].items()}
+            self._prev_in = {int(k): v.to(dev) for k, v in d["prev_in"].items()}
+        self.ctx.invalidate_order()      # option ids were written outside scg_step: the next step sorts afresh (same order)
+
+    def save(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load(self, path: str) -> None:
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+
     def q_update(self, k: int, s, action, r, cont, s_next, apply: bool = True) -> None:
         """Batched intra-option Q-learning update of VF k on explicit transitions (SPEC §5):
         delta = r + cont * max_a' Q_k(s',a') - Q_k(s,a);  W_k[a] += alpha/n * scale * sum delta*phi(s)."""

@@ -149,3 +149,45 @@ def test_batched_q_learning_learns_pinball():
         rates.append(float(goals) / (500 * 4096))
     assert bool(torch.isfinite(ag.W).all())
     assert rates[-1] > 3 * rates[0] and rates[-1] > 0.0015, rates     # chaotic in the rounding: loose on purpose
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_continues_bit_identically(tmp_path):
+    """SkillChainingAgent.save / load: a restored agent continues exactly like the uninterrupted one —
+    env state, weights, option bookkeeping and the trace buffers (RNG streams are keyed by (seed, env id, t))."""
+    import torch
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    from util import HP, chain_classifiers, random_weights
+
+    def make():
+        ag = SkillChainingAgent("pinball_simple", 3000, 3, seed=21, **HP)
+        ag.clf.copy_(torch.as_tensor(chain_classifiers(ag.map, 3), device="cuda:0"))
+        ag.enabled_mask = 0b1110
+        ag.set_option_parents([0, 0, 1, 1])                       # a small tree: 2 and 3 both chain to 1
+        ag.W.copy_(torch.as_tensor(random_weights(4, 2, std=0.05), device="cuda:0"))
+        ag.enable_tracing(32)
+        return ag
+
+    a = make()
+    a.domain.reset_random(seed=4, v_max=1.0)
+    for _ in range(9):
+        a.step_batch()
+        a.collect_examples(2, l_pos=8, l_neg=8)
+    path = str(tmp_path / "agent.pt")
+    a.save(path)
+    for _ in range(6):
+        a.step_batch()
+        a.collect_examples(2, l_pos=8, l_neg=8)
+    b = make()
+    b.load(path)
+    assert b.t == 9 and b.enabled_mask == 0b1110 and b.ctx.parents.tolist() == [0, 0, 1, 1]
+    for _ in range(6):
+        b.step_batch()
+        b.collect_examples(2, l_pos=8, l_neg=8)
+    torch.cuda.synchronize()
+    for f in SkillChainingAgent._STATE_FIELDS:
+        assert torch.equal(getattr(a.state, f), getattr(b.state, f)), f
+    assert torch.equal(a.W, b.W) and a.t == b.t
+    for ta, tb in zip(a.trace, b.trace):
+        assert torch.equal(ta, tb)
+    assert torch.equal(a._examples[2][0], b._examples[2][0]) and torch.equal(a._examples[2][1], b._examples[2][1])
