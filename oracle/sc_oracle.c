@@ -572,17 +572,20 @@ float sco_sigmoid(float z) {
 
 void sco_fit_initiation(int n_fit, const float *xy, const uint8_t *label, const int32_t *offsets,
                         float *w, int iters, float lr, float l2) {
-    enum { T = 256 };
+    /* SPEC §6 summation order: G = 8 groups of T = 1024 chains; chain gamma = j T + tau owns examples
+     * i = gamma (mod G T) in increasing i; 64 consecutive chains form a butterfly; a group's 16 butterfly results are
+     * added in order; the 8 group sums are added in order. */
+    enum { G = 8, T = 1024, GT = G * T };
+    float (*part)[6] = (float (*)[6])malloc(sizeof(float) * GT * 6);
     for (int q = 0; q < n_fit; ++q) {
         float *wq = w + SCO_CLF_STRIDE * q;
         int i0 = offsets[q], M = offsets[q + 1] - offsets[q];
         if (M <= 0) continue;
         float invM = 1.0f / (float)M;
         for (int it = 0; it < iters; ++it) {
-            float part[T][6];
-            for (int tau = 0; tau < T; ++tau) {
+            for (int gamma = 0; gamma < GT; ++gamma) {
                 float g[6] = {0, 0, 0, 0, 0, 0};
-                for (int i = tau; i < M; i += T) {
+                for (int i = gamma; i < M; i += GT) {
                     float xx = xy[2 * (size_t)(i0 + i)], yy = xy[2 * (size_t)(i0 + i) + 1];
                     float u = fmaf(xx, 2.0f, -1.0f), v = fmaf(yy, 2.0f, -1.0f);
                     float psi[6] = {1.0f, u, v, u * u, u * v, v * v};
@@ -590,23 +593,27 @@ void sco_fit_initiation(int n_fit, const float *xy, const uint8_t *label, const 
                     float e = sco_sigmoid(z) - (float)label[i0 + i];
                     for (int j = 0; j < 6; ++j) g[j] = fmaf(e, psi[j], g[j]);
                 }
-                for (int j = 0; j < 6; ++j) part[tau][j] = g[j];
+                for (int j = 0; j < 6; ++j) part[gamma][j] = g[j];
             }
             for (int j = 0; j < 6; ++j) {
-                float wave_sum[4];
-                for (int wv = 0; wv < 4; ++wv) {
-                    float pbuf[64], qbuf[64];
-                    for (int l = 0; l < 64; ++l) pbuf[l] = part[wv * 64 + l][j];
-                    for (int m = 1; m < 64; m <<= 1) {
-                        for (int l = 0; l < 64; ++l) qbuf[l] = pbuf[l] + pbuf[l ^ m];
-                        memcpy(pbuf, qbuf, sizeof pbuf);
+                float gs = 0.0f;
+                for (int grp = 0; grp < G; ++grp) {
+                    float ps = 0.0f;
+                    for (int wv = 0; wv < T / 64; ++wv) {
+                        float pbuf[64], qbuf[64];
+                        for (int l = 0; l < 64; ++l) pbuf[l] = part[grp * T + wv * 64 + l][j];
+                        for (int m = 1; m < 64; m <<= 1) {
+                            for (int l = 0; l < 64; ++l) qbuf[l] = pbuf[l] + pbuf[l ^ m];
+                            memcpy(pbuf, qbuf, sizeof pbuf);
+                        }
+                        ps = wv == 0 ? pbuf[0] : ps + pbuf[0];
                     }
-                    wave_sum[wv] = pbuf[0];
+                    gs = grp == 0 ? ps : gs + ps;
                 }
-                float g = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
                 float reg = (j > 0) ? l2 * wq[j] : 0.0f;
-                wq[j] = wq[j] - lr * ((g * invM) + reg);
+                wq[j] = wq[j] - lr * ((gs * invM) + reg);
             }
         }
     }
+    free(part);
 }

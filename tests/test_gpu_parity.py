@@ -82,6 +82,23 @@ def test_classifier_predict_and_fit_bit_exact():
     assert (pred.cpu().numpy()[:3000] == lab[:3000]).mean() > 0.93
 
 
+def test_fit_many_examples_and_many_problems_bit_exact():
+    """SPEC §6 geometry: 8 workgroups x 1024 chains per option. Covers several examples per chain (20 000), the part
+    beyond the 8 register-resident examples per chain (70 000 > 65 536), one example only, and more problems than one
+    launch batch holds (10 > 8)."""
+    ctx, orc, m = make_pair("pinball_simple", 256)
+    rng = np.random.default_rng(15)
+    sizes = [20000, 70000, 1, 300, 0, 9000, 64, 8192, 8193, 777]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    xy = rng.random((off[-1], 2)).astype(np.float32)
+    lab = (((xy[:, 0] - 0.45) ** 2 + (xy[:, 1] - 0.55) ** 2) < 0.28 ** 2).astype(np.uint8)
+    w_o = (rng.standard_normal((len(sizes), 8)) * 0.05).astype(np.float32)
+    w_d = dev(w_o.copy())
+    orc.fit_initiation(xy, lab, off, w_o, iters=12, lr=2.0, l2=1e-3)
+    ctx.fit_initiation(dev(xy).view(-1), dev(lab), dev(off), w_d.view(-1), iters=12, lr=2.0, l2=1e-3)
+    assert np.array_equal(w_d.cpu().numpy(), w_o)
+
+
 @pytest.mark.parametrize("n,k", [(1, 0), (700, 0), (700, 2)])
 def test_q_update_bit_exact(n, k):
     ctx, orc, m = make_pair("pinball_simple", 700, n_options=2)
