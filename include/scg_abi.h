@@ -153,6 +153,21 @@ int scg_harvest(scg_ctx *ctx, int32_t n_sel, const int32_t *sel_env, const float
                 int32_t ring_len, const int32_t *ev_len, int32_t l_pos, int32_t l_neg, float *out_xy,
                 uint8_t *out_label, void *stream);
 
+/* scg_collect_examples: the device-side creation trigger (SPEC §7), one launch, nothing returns to the host: every env
+ * whose `events` byte has one of `event_bits` set — with prev_in (u8[N], in/out) only on the step the bit goes up —
+ * appends its min(L, ev_len, ring_len) most recent ring states behind the *count (device int32, in/out) examples
+ * already in ex_xy[cap][2] / ex_label[cap] (1 = one of the last l_pos states, 0 = older), in env order; what does not
+ * fit is dropped. The trace buffers of scg_set_trace_buffers are read. */
+int scg_collect_examples(scg_ctx *ctx, uint32_t event_bits, uint8_t *prev_in, int32_t l_pos, int32_t l_neg,
+                         float *ex_xy, uint8_t *ex_label, int32_t *count, int32_t cap, void *stream);
+
+/* Gestation (SPEC §4.4; Konidaris & Barto 2009: a new option learns off-policy before it may run). Bit k of gest_mask:
+ * option k's classifier is in use (initiation / target tests, event bits) but the option is never selected; every env
+ * whose state lies in its initiation set contributes an off-policy TD item to VF k; succ_counts[k] (device int32[n_vf],
+ * caller-owned, may be NULL) counts the transitions that reached option k's target from inside its initiation set.
+ * The caller moves the bit from gest_mask to scg_step's enabled_mask when the count is high enough. */
+int scg_set_gestation(scg_ctx *ctx, uint32_t gest_mask, int32_t *succ_counts);
+
 /* ---- measurement hooks (bench.py's roofline leg) ----
  * scg_profile_reset(ctx, p) with p >= 1 makes every p-th following scg_step record a HIP event pair round
  * its fused kernel on the launch stream (each pair costs a few microseconds of queue bubble, so sampling

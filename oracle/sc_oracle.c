@@ -212,9 +212,10 @@ void sco_classifier_predict(int n, const float *x, const float *y, const float *
     for (int e = 0; e < n; ++e) out[e] = clf_z(w8, x[e], y[e]) > 0.0f;
 }
 
+/* membership test of a KNOWN option (enabled or gestating, SPEC §4.4) */
 static int in_set(const sco_params *p, const float *clf, int k, float x, float y) {
     if (k < 1 || k > p->n_options) return 0;
-    if (!((p->enabled_mask >> k) & 1u)) return 0;
+    if (!(((p->enabled_mask | p->gest_mask) >> k) & 1u)) return 0;
     return clf_z(clf + SCO_CLF_STRIDE * k, x, y) > 0.0f;
 }
 
@@ -421,6 +422,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         env_rec rec[SCO_BLOCK_ENVS];
         int o_t[SCO_BLOCK_ENVS], o_n[SCO_BLOCK_ENVS];
         float r0[SCO_BLOCK_ENVS], c0[SCO_BLOCK_ENVS], ro[SCO_BLOCK_ENVS], co[SCO_BLOCK_ENVS];
+        unsigned gs[SCO_BLOCK_ENVS];
+        float rg[SCO_BLOCK_ENVS][8], cg[SCO_BLOCK_ENVS][8];
         st_tab *tab_s = (st_tab *)malloc(sizeof(st_tab) * nb);
         st_tab *tab_n = (st_tab *)malloc(sizeof(st_tab) * nb);
         td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
@@ -474,12 +477,29 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             if (keep) on = o;
             else
                 for (int k = 1; k <= p->n_options; ++k) {
+                    if (!((p->enabled_mask >> k) & 1u)) continue;              /* a gestating option is never selected */
                     if (!in_set(p, clf, k, nx, ny)) continue;
                     if (p->parents[k] != 0 && in_set(p, clf, p->parents[k], nx, ny)) continue;
                     on = k; break;
                 }
             o_t[i] = o; o_n[i] = on;
             r0[i] = rew; c0[i] = dn ? 0.0f : p->gamma;
+            /* SPEC §4.4: gestating options that hold the ENTRY state in their initiation set learn off-policy from this
+             * transition, as if the env had been running them (no time-out); their successes are counted */
+            gs[i] = 0;
+            for (int k = 1; k <= p->n_options; ++k) {
+                if (!((p->gest_mask >> k) & 1u) || !in_set(p, clf, k, rec[i].s[0], rec[i].s[1])) continue;
+                int par = p->parents[k];
+                int succ = (par == 0) ? goal : in_set(p, clf, par, sx, sy);
+                int fail = !succ && !in_set(p, clf, k, sx, sy);
+                gs[i] |= 1u << k;
+                rg[i][k] = rew + (succ ? p->r_option_success : 0.0f);
+                cg[i][k] = (dn != 0 || succ || fail) ? 0.0f : p->gamma;
+                if (succ && p->gest_succ) {
+#pragma omp atomic
+                    p->gest_succ[k] += 1;
+                }
+            }
             /* SPEC §7: trajectory ring (position of s_t) and per-step events */
             if (p->ring_x) {
                 size_t row = (size_t)(ep_steps[e] & (p->ring_len - 1)) * N + e;
@@ -505,13 +525,15 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         for (int k = 0; k < n_vf; ++k) {
             int m = 0;
             for (int i = 0; i < nb; ++i) {
-                int upd = (k == 0) || (o_t[i] == k);
+                int own = (k == 0) || (o_t[i] == k);
+                int gst = !own && ((gs[i] >> k) & 1u);
+                int upd = own || gst;
                 int cache = (o_n[i] == k);
                 if (!upd && !cache) continue;
-                float cont = (k == 0) ? c0[i] : co[i];
+                float cont = (k == 0) ? c0[i] : (gst ? cg[i][k] : co[i]);
                 items[m].env = i; items[m].upd = upd; items[m].cache = cache;
                 items[m].tgt = upd && cont > 0.0f;
-                items[m].r = (k == 0) ? r0[i] : ro[i];
+                items[m].r = (k == 0) ? r0[i] : (gst ? rg[i][k] : ro[i]);
                 items[m].cont = cont;
                 ++m;
             }
@@ -549,6 +571,27 @@ void sco_harvest(int n_sel, const int32_t *sel_env, const float *ring_x, const f
             out_label[t] = ok ? (j < l_pos ? 1 : 0) : 255;
         }
     }
+}
+
+void sco_collect_examples(int n_envs, const uint8_t *events, uint8_t *prev_in, uint32_t bits, const float *ring_x,
+                          const float *ring_y, int ring_len, const int32_t *ev_len, int l_pos, int l_neg,
+                          float *ex_xy, uint8_t *ex_label, int32_t *count, int cap) {
+    const int L = l_pos + l_neg;
+    int pos = *count;
+    for (int e = 0; e < n_envs; ++e) {
+        int in = (events[e] & bits) != 0, hit = in;
+        if (prev_in) { hit = in && !prev_in[e]; prev_in[e] = (uint8_t)in; }
+        if (!hit) continue;
+        int v = L < ev_len[e] ? L : ev_len[e];
+        if (ring_len < v) v = ring_len;
+        for (int j = 0; j < v; ++j, ++pos) {
+            if (pos >= cap) continue;
+            size_t row = (size_t)((ev_len[e] - 1 - j) & (ring_len - 1)) * n_envs + e;
+            ex_xy[2 * (size_t)pos] = ring_x[row]; ex_xy[2 * (size_t)pos + 1] = ring_y[row];
+            ex_label[pos] = j < l_pos ? 1 : 0;
+        }
+    }
+    *count = pos < cap ? pos : cap;
 }
 
 /* ------------------------------------------------------------------ SPEC §6: logistic regression */

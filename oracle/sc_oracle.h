@@ -43,6 +43,8 @@ typedef struct {
     int32_t *ev_len;            /* [n_envs] */
     int32_t ring_len;           /* power of two */
     int32_t parents[8];         /* SPEC §4.2 option graph: target option of k (0 = goal); [0] unused */
+    uint32_t gest_mask;         /* SPEC §4.4: options in gestation */
+    int32_t *gest_succ;         /* [n_options + 1] success counters of gestating options (NULL = off) */
 } sco_params;
 
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
@@ -71,6 +73,12 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
 /* SPEC §7: examples from the trajectory ring for the listed envs: out_xy[n_sel][L][2], out_label[n_sel][L] */
 void sco_harvest(int n_sel, const int32_t *sel_env, const float *ring_x, const float *ring_y, int ring_len,
                  int n_envs, const int32_t *ev_len, int l_pos, int l_neg, float *out_xy, uint8_t *out_label);
+/* SPEC §7 device-side trigger: envs (in env order) whose events byte has one of `bits` set — with prev_in only on the step
+ * the bit goes up (prev_in is updated) — append their min(L, ev_len, ring_len) most recent ring states behind the *count
+ * examples already held; what does not fit into cap is dropped. */
+void sco_collect_examples(int n_envs, const uint8_t *events, uint8_t *prev_in, uint32_t bits, const float *ring_x,
+                          const float *ring_y, int ring_len, const int32_t *ev_len, int l_pos, int l_neg,
+                          float *ex_xy, uint8_t *ex_label, int32_t *count, int cap);
 /* SPEC §6: n_fit problems; offsets[n_fit+1] index xy/label; w[n_fit][8] in/out. */
 void sco_fit_initiation(int n_fit, const float *xy, const uint8_t *label, const int32_t *offsets,
                         float *w, int iters, float lr, float l2);

@@ -29,6 +29,7 @@ class Params(C.Structure):
         ("ring_x", C.c_void_p), ("ring_y", C.c_void_p), ("events", C.c_void_p), ("ev_len", C.c_void_p),
         ("ring_len", C.c_int32),
         ("parents", C.c_int32 * 8),
+        ("gest_mask", C.c_uint32), ("gest_succ", C.c_void_p),
     ]
 
 
@@ -154,6 +155,18 @@ class Oracle:
         """SPEC §4.2 option graph: parents[k] = target option of k (0 = goal)."""
         for k in range(8):
             self.p.parents[k] = max(int(parents[k]), 0) if k < len(parents) else 0
+
+    def set_gestation(self, gest_mask):
+        """SPEC §4.4: options in gestation + their success counters (self.gest_succ, int32[n_vf])."""
+        self.gest_succ = np.zeros(self.n_vf, np.int32)
+        self.p.gest_mask = gest_mask
+        self.p.gest_succ = self.gest_succ.ctypes.data
+
+    def collect_examples(self, bits, prev_in, l_pos, l_neg, ex_xy, ex_label, count):
+        """SPEC §7 device-side trigger, mirrored: appends to ex_xy[cap,2] / ex_label[cap]; count = np.int32[1] in/out."""
+        self.L.sco_collect_examples(self.p.n_envs, _p(self.events), _p(prev_in), C.c_uint32(bits), _p(self.ring_x),
+                                    _p(self.ring_y), self.p.ring_len, _p(self.ev_len), l_pos, l_neg, _p(ex_xy),
+                                    _p(ex_label), _p(count), len(ex_label))
 
     def set_trace(self, ring_len):
         """SPEC §7: allocate + attach trace buffers (ring_x, ring_y [ring_len, N], events [N], ev_len [N])."""

@@ -29,6 +29,8 @@ class SkillChainingAgent:
         self.W = torch.zeros((self.n_vf, NUM_ACTIONS, NUM_FEATURES), dtype=torch.float32, device=dev)
         self.clf = torch.zeros((self.n_vf, CLF_STRIDE), dtype=torch.float32, device=dev)
         self.enabled_mask = 0
+        self.gest_mask = 0            # SPEC §4.4: options in gestation
+        self._gest_need = {}
         self.t = 0
         self.group = group            # torch.distributed group for shared option-Q weights (or None)
         self.domain = PinballDomain(self.ctx)
@@ -42,75 +44,130 @@ class SkillChainingAgent:
         self.enabled_mask = (self.enabled_mask | (1 << k)) if enabled else (self.enabled_mask & ~(1 << k))
 
     # ------------------------------------------------------------------ skill discovery (outer loop, SPEC §7)
-    def enable_tracing(self, ring_len: int = 256) -> None:
-        """Attach the device-resident trajectory ring + per-step event flags (costs ~13 B/env-step)."""
+    def enable_tracing(self, ring_len: int = 256, max_examples: int = 65536) -> None:
+        """Attach the device-resident trajectory ring + per-step event flags (costs ~13 B/env-step) and the per-option
+        example buffers (max_examples each) the device-side trigger appends to."""
         self.trace = self.ctx.set_trace_buffers(ring_len)
-        self._examples = {}
-        self._prev_in = {}
+        self._ex_cap = int(max_examples)
+        self._ex = {}                     # k -> (xy[cap, 2], label[cap], count[1], prev_in[N] or None), all on the device
 
-    def collect_examples(self, k: int, l_pos: int = 32, l_neg: int = 32, max_envs: int = 4096) -> int:
-        """Call after a step_batch while option k is being created: envs whose step ended inside option k's
-        target region (goal disc if parent[k] = 0, else the parent's initiation set, on the step they ENTER it)
-        contribute their last l_pos ring states as positives and the l_neg states before those as negatives.
-        Returns #examples held."""
-        ring_x, ring_y, events, ev_len = self.trace
+    def _ex_buffers(self, k: int):
+        if k not in self._ex:
+            dev, cap = self.W.device, self._ex_cap
+            parent = int(self.ctx.parents[k])
+            self._ex[k] = (torch.zeros((cap, 2), dtype=torch.float32, device=dev),
+                           torch.zeros(cap, dtype=torch.uint8, device=dev),
+                           torch.zeros(1, dtype=torch.int32, device=dev),
+                           torch.zeros(self.n_envs, dtype=torch.uint8, device=dev) if parent else None)
+        return self._ex[k]
+
+    def collect_examples(self, k: int, l_pos: int = 32, l_neg: int = 32) -> None:
+        """Call after a step_batch while option k is being created: envs whose step ended inside option k's target
+        region (goal disc if parent[k] = 0, else the parent's initiation set, on the step they ENTER it) append their
+        last l_pos ring states as positives and the l_neg states before those as negatives to option k's example
+        buffer. Selection, compaction and the gather run in ONE kernel on the device (SPEC §7): nothing is read back,
+        the host is not in the per-step path; examples_held(k) fetches the count when the outer loop wants it."""
+        xy, lab, cnt, prev = self._ex_buffers(k)
         parent = int(self.ctx.parents[k])
-        bit = 1 if parent == 0 else (1 << parent)
-        hit = (events & bit) != 0
-        if parent:                                   # in-set bits stay up while the env is inside: keep entries only
-            prev = self._prev_in.get(k)
-            self._prev_in[k] = hit.clone()
-            hit = hit & ~prev if prev is not None else torch.zeros_like(hit)
-        sel = torch.nonzero(hit).flatten().to(torch.int32)[:max_envs]       # ascending env ids
-        if sel.numel():
-            xy, lab = self.ctx.harvest(sel.contiguous(), l_pos, l_neg)
-            keep = lab.view(-1) != 255
-            xy, lab = xy.view(-1, 2)[keep], lab.view(-1)[keep]
-            px, pl = self._examples.get(k, (xy[:0], lab[:0]))
-            self._examples[k] = (torch.cat([px, xy]), torch.cat([pl, lab]))
-        got = int(self._examples.get(k, (torch.empty(0),))[0].shape[0])
-        if self.group is not None:           # sharded agent: every rank sees the node-wide count, so that the outer
-            got = _dist.allreduce_sum_int(got, self.group, self.W.device)      # loop takes the same branch everywhere
+        self.ctx.collect_examples(1 if parent == 0 else (1 << parent), prev, l_pos, l_neg, xy.view(-1), lab, cnt)
+
+    def examples_held(self, k: int) -> int:
+        """Examples in option k's buffer (one device->host read; node-wide total when the agent is sharded, so that
+        every rank takes the same branch in the outer loop)."""
+        got = int(self._ex_buffers(k)[2].item())
+        if self.group is not None:
+            got = _dist.allreduce_sum_int(got, self.group, self.W.device)
         return got
 
-    def create_option(self, k: int, iters: int = 400, lr: float = 3.0, l2: float = 1e-4) -> float:
-        """Fit initiation classifier k on the collected examples (GPU logistic regression), start its value
-        function from the root's, enable it. Returns the training accuracy."""
-        xy, lab = self._examples.get(k, (torch.zeros((0, 2), dtype=torch.float32, device=self.W.device),
-                                          torch.zeros((0,), dtype=torch.uint8, device=self.W.device)))
+    def examples(self, k: int):
+        """(xy[n, 2], label[n]) collected for option k so far (views of the device buffers)."""
+        xy, lab, cnt, _ = self._ex_buffers(k)
+        n = int(cnt.item())
+        return xy[:n], lab[:n]
+
+    def create_option(self, k: int, iters: int = 400, lr: float = 3.0, l2: float = 1e-4, gestation: int = 0) -> float:
+        """Fit initiation classifier k on the collected examples (GPU logistic regression) and start its value function
+        from the root's. With gestation = 0 the option is enabled at once; with gestation = G > 0 it first gestates
+        (SPEC §4.4, Konidaris & Barto 2009): its classifier is in use, it is never selected, every transition from inside
+        its initiation set updates its value function off-policy, and poll_gestation() enables it once G such
+        transitions have reached its target. Returns the training accuracy."""
+        xy, lab = self.examples(k)
         if self.group is not None:           # fit on the examples of ALL ranks (rank order): identical classifiers everywhere
             xy, lab = _dist.allgather_rows(xy.contiguous(), self.group), _dist.allgather_rows(lab.contiguous(), self.group)
         clf = self.options[k].initiation_classifier
         clf.fit(xy.contiguous(), lab.contiguous(), iters=iters, lr=lr, l2=l2)
         self.W[k].copy_(self.W[0])
-        self.enable_option(k)
+        if gestation > 0:
+            self._gest_need[k] = int(gestation)
+            self.gest_mask |= 1 << k
+            succ = self.ctx.set_gestation(self.gest_mask)
+            succ[k] = 0
+        else:
+            self.enable_option(k)
         pred = clf.predict(xy[:, 0].contiguous(), xy[:, 1].contiguous())
         return float((pred == lab).float().mean())
 
+    def poll_gestation(self) -> list:
+        """Enable every gestating option whose success count has reached its requirement (one device->host read;
+        counts are summed over the ranks of a sharded agent). Returns the options enabled by this call."""
+        if not self.gest_mask:
+            return []
+        succ = self.ctx.set_gestation(self.gest_mask).cpu()
+        done = []
+        for k in range(1, self.n_options + 1):
+            if not (self.gest_mask >> k) & 1:
+                continue
+            n = int(succ[k])
+            if self.group is not None:
+                n = _dist.allreduce_sum_int(n, self.group, self.W.device)
+            if n >= self._gest_need[k]:
+                self.gest_mask &= ~(1 << k)
+                self.enable_option(k)
+                done.append(k)
+        if done:
+            self.ctx.set_gestation(self.gest_mask)
+        return done
+
     def chain_skills(self, steps_per_option: int = 300, min_examples: int = 2000, max_examples: int = 40000,
-                     l_pos: int = 24, l_neg: int = 24, start_coverage: float = 0.5, **fit) -> list:
+                     l_pos: int = 24, l_neg: int = 24, start_coverage: float = 0.5, poll_every: int = 8,
+                     gestation: int = 0, gestation_steps: int = 200, **fit) -> list:
         """The outer loop of skill chaining (Konidaris & Barto 2009, the paper README.md:2 names), host-side
         policy over the device-resident pieces: for each not-yet-enabled option k in index order, run
         step-batches until enough trajectories have entered k's target (its parent in the skill graph),
-        fit initiation set k on them, enable the option, and stop once the start states are covered.
-        Returns one report dict per created option."""
+        fit initiation set k on them, let it gestate (`gestation` successes, at most `gestation_steps` step-batches)
+        or enable it at once, and stop once the start states are covered. The host looks at the device-side
+        counters only every `poll_every` step-batches. Returns one report dict per created option."""
         report = []
         sx = torch.as_tensor(self.map.starts[:, 0].copy(), device=self.W.device)
         sy = torch.as_tensor(self.map.starts[:, 1].copy(), device=self.W.device)
+        max_examples = min(max_examples, self._ex_cap)
         for k in range(1, self.n_options + 1):
-            if (self.enabled_mask >> k) & 1:
+            if ((self.enabled_mask | self.gest_mask) >> k) & 1:
                 continue
             got = steps = 0
             while steps < steps_per_option and got < max_examples:
-                self.step_batch()
-                got = self.collect_examples(k, l_pos, l_neg)
-                steps += 1
+                for _ in range(min(poll_every, steps_per_option - steps)):
+                    self.step_batch()
+                    self.collect_examples(k, l_pos, l_neg)
+                    steps += 1
+                got = self.examples_held(k)
+                self.poll_gestation()
             if got < min_examples:
                 break
-            acc = self.create_option(k, **fit)
+            acc = self.create_option(k, gestation=gestation, **fit)
+            gsteps = 0
+            while (self.gest_mask >> k) & 1 and gsteps < gestation_steps:
+                for _ in range(poll_every):
+                    self.step_batch()
+                gsteps += poll_every
+                self.poll_gestation()
+            if (self.gest_mask >> k) & 1:            # did not see enough successes: enable anyway, as the paper's
+                self.gest_mask &= ~(1 << k)          # fixed-length gestation period would
+                self.ctx.set_gestation(self.gest_mask)
+                self.enable_option(k)
             cov = float(self.options[k].initiation_classifier.predict(sx, sy).float().mean())
             report.append(dict(option=k, parent=int(self.ctx.parents[k]), steps=steps, examples=got,
-                               accuracy=acc, start_coverage=cov))
+                               accuracy=acc, start_coverage=cov, gestation_steps=gsteps))
             if cov >= start_coverage:
                 break
         return report
@@ -163,14 +220,19 @@ class SkillChainingAgent:
         if getattr(self, "trace", None) is not None:
             ring_x, ring_y, events, ev_len = self.trace
             d["trace"] = {"ring_x": ring_x.cpu(), "ring_y": ring_y.cpu(), "events": events.cpu(), "ev_len": ev_len.cpu()}
-            d["examples"] = {int(k): (xy.cpu(), lab.cpu()) for k, (xy, lab) in self._examples.items()}
-            d["prev_in"] = {int(k): v.cpu() for k, v in self._prev_in.items()}
+            d["ex_cap"] = self._ex_cap
+            d["examples"] = {int(k): (xy[: int(cnt.item())].cpu(), lab[: int(cnt.item())].cpu())
+                             for k, (xy, lab, cnt, _) in self._ex.items()}
+            d["prev_in"] = {int(k): v[3].cpu() for k, v in self._ex.items() if v[3] is not None}
+        d["gest_mask"] = int(self.gest_mask)
+        d["gest_need"] = {int(k): int(v) for k, v in self._gest_need.items()}
+        if self.gest_mask:
+            d["gest_succ"] = self.ctx.set_gestation(self.gest_mask).cpu()
         return d
 
     def load_state_dict(self, d: dict) -> None:
         if d.get("format") != 1 or d["n_envs"] != self.n_envs or d["n_options"] != self.n_options:
             raise ValueError("checkpoint does not match this agent (format / n_envs / n_options)")
-        dev = self.W.device
         self.W.copy_(d["W"]); self.clf.copy_(d["clf"])
         for f in self._STATE_FIELDS:
             getattr(self.state, f).copy_(d["state"][f])
@@ -178,11 +240,18 @@ class SkillChainingAgent:
         if self.n_options:
             self.ctx.set_option_parents([int(v) for v in d["parents"]])
         if "trace" in d:
-            self.enable_tracing(int(d["trace"]["ring_x"].shape[0]))
+            self.enable_tracing(int(d["trace"]["ring_x"].shape[0]), int(d["ex_cap"]))
             for name, buf in zip(("ring_x", "ring_y", "events", "ev_len"), self.trace):
                 buf.copy_(d["trace"][name])
-            self._examples = {int(k): (xy.to(dev), lab.to(dev)) for k, (xy, lab) in d["examples"].items()}
-            self._prev_in = {int(k): v.to(dev) for k, v in d["prev_in"].items()}
+            for k, (xy, lab) in d["examples"].items():
+                bxy, blab, cnt, prev = self._ex_buffers(int(k))
+                bxy[: xy.shape[0]].copy_(xy); blab[: lab.shape[0]].copy_(lab); cnt.fill_(int(lab.shape[0]))
+                if prev is not None and int(k) in d["prev_in"]:
+                    prev.copy_(d["prev_in"][int(k)])
+        self.gest_mask = int(d.get("gest_mask", 0))
+        self._gest_need = {int(k): int(v) for k, v in d.get("gest_need", {}).items()}
+        if self.gest_mask:
+            self.ctx.set_gestation(self.gest_mask).copy_(d["gest_succ"])
         self.ctx.invalidate_order()      # option ids were written outside scg_step: the next step sorts afresh (same order)
 
     def save(self, path: str) -> None:

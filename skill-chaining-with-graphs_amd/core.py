@@ -164,6 +164,32 @@ class ScgContext:
                    l_pos, l_neg, _ptr(xy), _ptr(lab), self._stream())
         return xy, lab
 
+    def collect_examples(self, event_bits: int, prev_in: Optional[torch.Tensor], l_pos: int, l_neg: int,
+                         ex_xy: torch.Tensor, ex_label: torch.Tensor, count: torch.Tensor) -> None:
+        """SPEC §7 device-side trigger: envs whose events byte has one of `event_bits` set (with prev_in: on the step the
+        bit goes up) append their most recent ring states to ex_xy[cap, 2] / ex_label[cap] behind the count[0] examples
+        already there (device int32[1], in/out). One launch, nothing comes back to the host."""
+        if getattr(self, "_trace", None) is None:
+            raise ScgError("collect_examples: trace buffers are not attached (set_trace_buffers)")
+        cap = ex_label.numel()
+        self._chk(ex_xy, torch.float32, 2 * cap, "ex_xy"); self._chk(ex_label, torch.uint8, cap, "ex_label")
+        self._chk(count, torch.int32, 1, "count")
+        if prev_in is not None:
+            self._chk(prev_in, torch.uint8, self.n_envs, "prev_in")
+        if l_pos < 0 or l_neg < 0 or l_pos + l_neg < 1 or not (0 < event_bits < 64):
+            raise ScgError("collect_examples: bad argument")
+        self._call("scg_collect_examples", C.c_uint32(event_bits), _ptr(prev_in), l_pos, l_neg, _ptr(ex_xy), _ptr(ex_label),
+                   _ptr(count), cap, self._stream())
+
+    def set_gestation(self, gest_mask: int) -> torch.Tensor:
+        """SPEC §4.4: options in gestation (known, never selected, learning off-policy). Returns the device int32[n_vf]
+        success counters the fused step adds to (kept across calls; zero an entry when its option starts gestating)."""
+        if not hasattr(self, "_gest_succ"):
+            self._gest_succ = torch.zeros(self.n_vf, dtype=torch.int32, device=self.device)
+        self._call("scg_set_gestation", C.c_uint32(gest_mask), _ptr(self._gest_succ))
+        self.gest_mask = gest_mask
+        return self._gest_succ
+
     def grad_buffers(self):
         """(G[n_vf,5,1296] float32, n_k[n_vf] int32): caller-owned torch tensors that scg_step(LEARN)
         fills with the rank-local gradient sum and update counts (the all-reduce operands, SPEC §5)."""

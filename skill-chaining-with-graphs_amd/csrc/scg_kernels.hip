@@ -34,9 +34,9 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // LDS map of the step kernel (bytes)
 constexpr int OFF_EDGES = 0;                                   // float[256][8]
 constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][128], sn[4][128]
-constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co [128]
-constexpr int OFF_INT = OFF_RC + 4 * BLOCK_ENVS * 4;           // uint8 a, ot, on [128] (+pad)
-constexpr int OFF_Z1 = OFF_INT + 4 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
+constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co (per env), rk,ck (per env, this pass) [128]
+constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia [128]
+constexpr int OFF_Z1 = OFF_INT + 5 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
 // region W: W_k staged in A-operand order (12 tiles x 9 k-blocks x 64 lanes), read once per wave per pass
 // region R, used by one phase at a time (R reaches back over region W, which is dead once the A operands are in registers):
 //   E, U1 : per wave CDk[36][16] + ABq[16][36] floats (4 x 4608 B), behind region W
@@ -114,6 +114,8 @@ struct StepArgs {
     unsigned long long *stamps;    // diagnostic build only
     int32_t n, n_vf, k_lo, k_hi;
     uint32_t enabled, learn;
+    uint32_t gest;                 // SPEC §4.4: options in gestation (classifier known, not selectable, learning off-policy)
+    int32_t *gest_succ;            // [n_vf] successes seen from inside a gestating option's initiation set (atomic counts)
     uint32_t parents;              // 3 bits per option k at [3k, 3k+3): target option of k (0 = the task goal)
     uint64_t t, seed;
     int64_t env_base;
@@ -195,8 +197,11 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     float *s_s = reinterpret_cast<float *>(smem + OFF_S);              // [8][128]: s then sn
     float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
     float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
+    float *s_rk = s_co + BLOCK_ENVS, *s_ck = s_rk + BLOCK_ENVS;       // reward / continuation of the pass's value function
     uint8_t *s_a = reinterpret_cast<uint8_t *>(smem + OFF_INT);
     uint8_t *s_ot = s_a + BLOCK_ENVS, *s_on = s_ot + BLOCK_ENVS;
+    uint8_t *s_gs = s_on + BLOCK_ENVS;      // bit k: gestating option k holds s in its initiation set (off-policy item)
+    uint8_t *s_ia = s_gs + BLOCK_ENVS;      // bit 0: goal; bit k: in_k(s')
     float2 *s_z1 = reinterpret_cast<float2 *>(smem + OFF_Z1);
     float *s_R = reinterpret_cast<float *>(smem + OFF_R);
     uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
@@ -271,13 +276,15 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_s[6 * BLOCK_ENVS + i] = nvx; s_s[7 * BLOCK_ENVS + i] = nvy;
                 // options (SPEC §4.2), branch-free: membership bit masks of s' and s_next over all options
                 // (classifier rows come from LDS), then the success / failure / selection rules on the masks
-                unsigned inA = 0, inB = 0;            // bit k: in_k(s'), in_k(s_next)
+                unsigned inA = 0, inB = 0, inS = 0;   // bit k: in_k(s'), in_k(s_next); gestating k only: in_k(s)
+                const unsigned known = A.enabled | A.gest;
 #pragma unroll
                 for (int k = 1; k < MAX_VF; ++k) {
-                    if (k < A.n_vf && ((A.enabled >> k) & 1u)) {
+                    if (k < A.n_vf && ((known >> k) & 1u)) {
                         const float *w = s_clf + CLF_STRIDE * k;
                         if (clf_z(w, sx, sy) > 0.0f) inA |= 1u << k;
                         if (clf_z(w, nx, ny) > 0.0f) inB |= 1u << k;
+                        if (((A.gest >> k) & 1u) && clf_z(w, s_s[0 * BLOCK_ENVS + i], s_s[1 * BLOCK_ENVS + i]) > 0.0f) inS |= 1u << k;
                     }
                 }
                 bool keep = false;
@@ -299,10 +306,18 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     const unsigned par = (A.parents >> (3 * k)) & 7u;
                     if (par != 0 && ((inB >> par) & 1u)) tgtB |= 1u << k;
                 }
-                const unsigned sel = inB & ~tgtB;
+                const unsigned sel = inB & ~tgtB & A.enabled;         // a gestating option is never selected
                 const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
-                atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)));
+                s_gs[i] = (uint8_t)inS; s_ia[i] = (uint8_t)((inA & 0x3Eu) | (goal ? 1u : 0u));
+                atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)) | inS);
+                if (inS && A.gest_succ) {                             // SPEC §4.4: gestation successes (integer counts: order-free)
+#pragma unroll
+                    for (int k = 1; k < MAX_VF; ++k) {
+                        const unsigned par = (A.parents >> (3 * k)) & 7u;
+                        if (((inS >> k) & 1u) && ((par == 0) ? goal : (bool)((inA >> par) & 1u))) atomicAdd(&A.gest_succ[k], 1);
+                    }
+                }
                 s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
                 // results -> staging record at this env's POSITION (full-line stores); commit_row scatters them
                 // to the caller's arrays in env order. (Direct 4-byte stores from here dirtied every 64-byte line
@@ -326,17 +341,17 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
                 s_s[4 * BLOCK_ENVS + i] = A.xn[e]; s_s[5 * BLOCK_ENVS + i] = A.yn[e];
                 s_s[6 * BLOCK_ENVS + i] = A.vxn[e]; s_s[7 * BLOCK_ENVS + i] = A.vyn[e];
-                s_a[i] = A.action[e]; s_ot[i] = (uint8_t)A.k_lo; s_on[i] = 255;
+                s_a[i] = A.action[e]; s_ot[i] = (uint8_t)A.k_lo; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
                 const float r = A.reward[e], c = A.cont_in[e];
                 s_r0[i] = r; s_c0[i] = c; s_ro[i] = r; s_co[i] = c;
             } else {
                 s_s[4 * BLOCK_ENVS + i] = A.x[e]; s_s[5 * BLOCK_ENVS + i] = A.y[e];
                 s_s[6 * BLOCK_ENVS + i] = A.vx[e]; s_s[7 * BLOCK_ENVS + i] = A.vy[e];
-                s_a[i] = 0; s_ot[i] = 255; s_on[i] = (uint8_t)A.k_lo;
+                s_a[i] = 0; s_ot[i] = 255; s_on[i] = (uint8_t)A.k_lo; s_gs[i] = 0; s_ia[i] = 0;
                 s_r0[i] = 0.0f; s_c0[i] = 0.0f; s_ro[i] = 0.0f; s_co[i] = 0.0f;
             }
         } else {
-            s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255;
+            s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
         }
     }
     block_lds_sync();
@@ -400,8 +415,21 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         int at = -1;
         if (tid < nb) {
             const int ot = s_ot[tid], on = s_on[tid];
-            up = (MODE != MODE_QVAL) && A.learn && ((MODE == MODE_FUSED && k == 0) || ot == k);
-            const float cont = (k == 0) ? s_c0[tid] : s_co[tid];
+            const bool own = (MODE == MODE_FUSED && k == 0) || ot == k;
+            const bool gst = MODE == MODE_FUSED && !own && ((s_gs[tid] >> k) & 1);       // SPEC §4.4 off-policy item
+            up = (MODE != MODE_QVAL) && A.learn && (own || gst);
+            float rk = s_r0[tid], cont = s_c0[tid];
+            if (MODE == MODE_FUSED && k != 0) {
+                if (ot == k) { rk = s_ro[tid]; cont = s_co[tid]; }
+                else {                                    // as if the env ran option k: no time-out, no selection
+                    const unsigned ia = s_ia[tid], par = (A.parents >> (3 * k)) & 7u;
+                    const bool succ = (par == 0) ? (ia & 1u) : ((ia >> par) & 1u);
+                    const bool fail = !succ && !((ia >> k) & 1u);
+                    rk = rk + (succ ? A.r_succ : 0.0f);
+                    cont = (cont == 0.0f || succ || fail) ? 0.0f : A.gamma;
+                }
+            }
+            s_rk[tid] = rk; s_ck[tid] = cont;
             ev = (on == k) || (up && cont > 0.0f);
             at = s_a[tid];
         }
@@ -638,8 +666,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                     float *pd = ptab + cp * US + 2 * slot, *cdst = ctab + cp * US + 2 * slot;
                     if (j < rl) {
                         const int li = ro + j, il = s_ulist[li];
-                        const float rr = (k == 0) ? s_r0[il] : s_ro[il];
-                        const float cont = (k == 0) ? s_c0[il] : s_co[il];
+                        const float rr = s_rk[il], cont = s_ck[il];
                         const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
                         const float d = target - s_qsa[li];
                         float2 ab[6], cd[6];
@@ -1144,6 +1171,60 @@ __global__ __launch_bounds__(256) void harvest_kernel(int n_sel, const int32_t *
     out_label[t] = ok ? (j < l_pos ? 1 : 0) : 255;
 }
 
+// SPEC §7 device-side trigger + harvest in one launch (no host round trip per step): ONE workgroup walks the envs in
+// env order, 1024 at a time. An env is selected when (events & bits) != 0 — with `prev_in` given, only on the step it
+// ENTERS that state (prev_in is updated). A selected env contributes its v = min(L, ev_len, ring_len) most recent ring
+// states (age j < l_pos: label 1, else 0), appended behind the *count examples the buffer already holds, in env order,
+// ages ascending; what does not fit into `cap` is dropped. Ordered compaction = ballots + popcounts inside a wave, a
+// 16-entry scan across the waves, a running offset across the chunks: deterministic.
+__global__ __launch_bounds__(1024) void collect_kernel(int n, const uint8_t *events, uint8_t *prev_in, uint32_t bits,
+                                                       const float *ring_x, const float *ring_y, int ring_len,
+                                                       const int32_t *ev_len, int l_pos, int l_neg, float *ex_xy,
+                                                       uint8_t *ex_label, int32_t *count, int cap) {
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = l_pos + l_neg;
+    if (tid == 0) s_base = *count;
+    __syncthreads();
+    for (int e0 = 0; e0 < n; e0 += 1024) {
+        const int e = e0 + tid;
+        int v = 0;
+        if (e < n) {
+            const bool in = (events[e] & bits) != 0;
+            bool hit = in;
+            if (prev_in) { hit = in && !prev_in[e]; prev_in[e] = in ? 1 : 0; }
+            if (hit) v = min(min(L, ev_len[e]), ring_len);
+        }
+        // exclusive prefix of v inside the wave (6 shuffle steps), then across the 16 waves
+        int incl = v;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int t = __shfl_up(incl, m, 64);
+            if (lane >= m) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 16; ++w2) { const int t = s_wsum[w2]; if (w2 < wave) woff += t; tot += t; }
+        const int base = s_base;
+        const int pos0 = base + woff + incl - v;
+        for (int j = 0; j < v; ++j) {
+            const int pos = pos0 + j;
+            if (pos < cap) {
+                const size_t row = (size_t)((ev_len[e] - 1 - j) & (ring_len - 1)) * n + e;
+                ex_xy[2 * (size_t)pos] = ring_x[row]; ex_xy[2 * (size_t)pos + 1] = ring_y[row];
+                ex_label[pos] = j < l_pos ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base = min(base + tot, cap);
+        __syncthreads();
+    }
+    if (tid == 0) *count = s_base;
+}
+
 // ------------------------------------------------------------------------------------------------
 // un-fused kernels
 __global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y, float *vx, float *vy,
@@ -1301,6 +1382,8 @@ struct scg_ctx {
     bool order_valid;              // d_perm already holds the order of the ids in order_ids (made by the last learning step)
     const int32_t *order_ids;
     uint32_t parents;              // packed option targets (default: the chain k -> k-1)
+    uint32_t gest;                 // SPEC §4.4 options in gestation
+    int32_t *gest_succ;            // caller-owned device counters [n_vf] (NULL = none)
     float *ring_x, *ring_y;        // SPEC §7 caller-owned trace buffers (NULL = off)
     uint8_t *events;
     int32_t *ev_len;
@@ -1522,6 +1605,7 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.edges = c->d_edges; A.starts = c->d_starts; A.cellmask = c->d_cellmask;
     A.slabs = c->d_slabs; A.cnts = c->d_cnts;
     A.parents = c->parents;
+    A.gest = c->gest; A.gest_succ = c->gest_succ;
     A.ring_x = c->ring_x; A.ring_y = c->ring_y; A.events = c->events; A.ev_len = c->ev_len;
     A.ring_mask = c->ring_len > 0 ? c->ring_len - 1 : 0;
     A.stamps = c->d_stamps;
@@ -1651,6 +1735,27 @@ int scg_set_option_parents(scg_ctx *c, const int32_t *parents) {
         if (p != 0) return fail(c, SCG_ERR_INVALID, "scg_set_option_parents: the option graph has a cycle");
     }
     c->parents = packed;
+    return SCG_OK;
+}
+
+int scg_set_gestation(scg_ctx *c, uint32_t gest_mask, int32_t *succ_counts) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_gestation: null ctx");
+    if (gest_mask & ~(((1u << c->n_vf) - 1u) & ~1u)) return fail(c, SCG_ERR_INVALID, "scg_set_gestation: mask names no option of this context");
+    c->gest = gest_mask; c->gest_succ = succ_counts;
+    return SCG_OK;
+}
+
+int scg_collect_examples(scg_ctx *c, uint32_t event_bits, uint8_t *prev_in, int32_t l_pos, int32_t l_neg, float *ex_xy,
+                         uint8_t *ex_label, int32_t *count, int32_t cap, void *stream) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_collect_examples: null ctx");
+    if (!c->ring_x || !c->events) return fail(c, SCG_ERR_STATE, "scg_collect_examples: trace buffers are not attached");
+    if (!event_bits || l_pos < 0 || l_neg < 0 || l_pos + l_neg < 1 || !ex_xy || !ex_label || !count || cap < 0)
+        return fail(c, SCG_ERR_INVALID, "scg_collect_examples: bad argument");
+    SCG_ON_DEVICE(c, "scg_collect_examples");
+    hipLaunchKernelGGL(collect_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), c->cfg.n_envs,
+                       c->events, prev_in, event_bits, c->ring_x, c->ring_y, c->ring_len, c->ev_len, l_pos, l_neg, ex_xy,
+                       ex_label, count, cap);
+    SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
 

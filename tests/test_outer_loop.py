@@ -84,6 +84,122 @@ def test_trace_and_harvest_bit_exact_on_gpu():
     assert np.array_equal(W_d.cpu().numpy(), W_o)
 
 
+def test_collect_examples_matches_select_then_harvest():
+    """The device-side trigger (one pass: select, compact, gather) against its two-step definition on the oracle:
+    entering envs in env order, each contributing its valid harvest rows (a prefix of the ages)."""
+    n, steps, H = 400, 30, 8
+    orc, m = make_oracle("pinball_simple", n_envs=n, n_options=2, seed=4, enabled_mask=0b110, max_episode_steps=20)
+    orc.set_trace(H)
+    st = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 31, vmax=1.0)
+    st["x"][:], st["y"][:], st["vx"][:], st["vy"][:] = x, y, vx, vy
+    W, clf = random_weights(3, 32, std=0.05), chain_classifiers(m, 2)
+    cap = 120
+    ex_xy, ex_lab, cnt = np.zeros((cap, 2), np.float32), np.zeros(cap, np.uint8), np.zeros(1, np.int32)
+    prev = np.zeros(n, np.uint8)
+    want_xy, want_lab, was_in = [], [], np.zeros(n, bool)
+    for t in range(steps):
+        G, n_k = orc.step(st, W, clf, t)
+        orc.apply(W, G, n_k)
+        orc.collect_examples(0b10, prev, 3, 4, ex_xy, ex_lab, cnt)        # envs ENTERING initiation set 1
+        now_in = (orc.events & 2) != 0
+        sel = np.nonzero(now_in & ~was_in)[0].astype(np.int32)
+        was_in = now_in
+        if len(sel):
+            xy, lab = orc.harvest(sel, 3, 4)
+            keep = lab.reshape(-1) != 255
+            want_xy.append(xy.reshape(-1, 2)[keep]); want_lab.append(lab.reshape(-1)[keep])
+    want_xy, want_lab = np.concatenate(want_xy), np.concatenate(want_lab)
+    assert len(want_lab) > cap                                            # the buffer overflows: the tail is dropped
+    assert cnt[0] == cap and np.array_equal(ex_xy, want_xy[:cap]) and np.array_equal(ex_lab, want_lab[:cap])
+    assert np.array_equal(prev.astype(bool), was_in)
+
+
+def test_gestating_option_learns_off_policy_and_is_never_selected():
+    """SPEC §4.4 on the oracle: option 2 gestates — nobody runs it, yet VF 2 gets update items (the envs inside its
+    initiation set), its successes are counted, and its classifier still serves as a membership test (events bit 2)."""
+    n = 600
+    orc, m = make_oracle("pinball_simple", n_envs=n, n_options=2, seed=6, enabled_mask=0b010)
+    orc.set_gestation(0b100)
+    orc.set_trace(8)
+    st = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 33, vmax=1.0)
+    st["x"][:], st["y"][:], st["vx"][:], st["vy"][:] = x, y, vx, vy
+    W, clf = random_weights(3, 34, std=0.05), chain_classifiers(m, 2)
+    W2_before = W[2].copy()
+    n2 = 0
+    for t in range(25):
+        inside = orc.classifier_predict(st["x"].copy(), st["y"].copy(), clf[2]).astype(bool)
+        G, n_k = orc.step(st, W, clf, t)
+        orc.apply(W, G, n_k)
+        assert not np.any(st["option_id"] == 2)                            # never selected
+        assert n_k[2] == inside.sum()                                      # one off-policy item per env inside I_2
+        n2 += int(n_k[2])
+    assert n2 > 0 and not np.array_equal(W[2], W2_before)
+    assert orc.gest_succ[2] > 0 and orc.gest_succ[0] == 0 and orc.gest_succ[1] == 0
+    assert np.any(orc.events & 4)
+
+
+@pytest.mark.gpu
+def test_gestation_and_device_side_collect_bit_exact_on_gpu():
+    import torch
+    from gpu_util import assert_state_equal, dev, make_pair, state_to_device
+    n, steps, H, nopt = 1500, 30, 16, 3
+    enabled, gest = 0b0010, 0b1100                                        # option 1 runs, 2 and 3 gestate
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=nopt, seed=8, enabled_mask=enabled, max_episode_steps=30)
+    orc.set_gestation(gest); orc.set_trace(H)
+    ctx.set_trace_buffers(H)
+    succ_d = ctx.set_gestation(gest)
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 35, vmax=1.0)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    W_o, clf = random_weights(nopt + 1, 36, std=0.05), chain_classifiers(m, nopt)
+    st_d, W_d, clf_d = state_to_device(st_o, ctx), dev(W_o.copy()), dev(clf)
+    cap = 5000
+    ex_xy_o, ex_lab_o, cnt_o, prev_o = np.zeros((cap, 2), np.float32), np.zeros(cap, np.uint8), np.zeros(1, np.int32), np.zeros(n, np.uint8)
+    ex_xy_d, ex_lab_d = torch.zeros((cap, 2), device="cuda:0"), torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+    cnt_d, prev_d = torch.zeros(1, dtype=torch.int32, device="cuda:0"), torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    gp = ctx.grad_buffers()
+    for t in range(steps):
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        orc.apply(W_o, G, n_k)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), enabled, t)
+        orc.collect_examples(0b100, prev_o, 6, 5, ex_xy_o, ex_lab_o, cnt_o)          # envs entering I_2 (gestating, known)
+        ctx.collect_examples(0b100, prev_d, 6, 5, ex_xy_d.view(-1), ex_lab_d, cnt_d)
+        assert np.array_equal(gp[1].cpu().numpy(), n_k), t
+    torch.cuda.synchronize()
+    assert_state_equal(st_d, st_o, msg="gestation rollout")
+    assert np.array_equal(W_d.cpu().numpy(), W_o)
+    assert np.array_equal(succ_d.cpu().numpy(), orc.gest_succ) and orc.gest_succ[2] + orc.gest_succ[3] > 0
+    assert int(cnt_d.item()) == int(cnt_o[0]) > 0
+    k = int(cnt_o[0])
+    assert np.array_equal(ex_xy_d.cpu().numpy()[:k], ex_xy_o[:k]) and np.array_equal(ex_lab_d.cpu().numpy()[:k], ex_lab_o[:k])
+    assert np.array_equal(prev_d.cpu().numpy(), prev_o)
+    # the first collect with a goal trigger (no prev_in) on top of a non-empty buffer
+    orc.collect_examples(0b1, None, 4, 4, ex_xy_o, ex_lab_o, cnt_o)
+    ctx.collect_examples(0b1, None, 4, 4, ex_xy_d.view(-1), ex_lab_d, cnt_d)
+    k = int(cnt_o[0])
+    assert int(cnt_d.item()) == k and np.array_equal(ex_xy_d.cpu().numpy()[:k], ex_xy_o[:k])
+
+
+@pytest.mark.gpu
+def test_chain_skills_with_gestation():
+    """The outer loop with a gestation period (SPEC §4.4): created options first learn off-policy, then get enabled by
+    the success counters (or by the step limit), and are executed afterwards."""
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    agent = SkillChainingAgent("pinball_empty", 8192, 2, seed=5, epsilon=1.0, alpha=1e-4, max_episode_steps=400)
+    agent.enable_tracing(64)
+    agent.domain.reset_random(seed=11, v_max=0.5)
+    report = agent.chain_skills(steps_per_option=250, min_examples=2000, max_examples=20000, start_coverage=2.0,
+                                gestation=200, gestation_steps=120)
+    assert len(report) >= 1 and agent.gest_mask == 0, report
+    assert all(0 < r["gestation_steps"] <= 120 for r in report), report
+    assert all((agent.enabled_mask >> r["option"]) & 1 for r in report)
+    for _ in range(5):
+        agent.step_batch()
+    assert int((agent.state.option_id == 1).sum()) > 0
+
+
 @pytest.mark.gpu
 def test_discover_first_option_end_to_end():
     """Skill chaining's first link, on the GPU only: run the root policy until envs reach the goal, harvest
@@ -94,15 +210,17 @@ def test_discover_first_option_end_to_end():
     agent.enable_tracing(64)
     agent.domain.reset_random(seed=9, v_max=0.5)
     got = 0
-    for _ in range(150):
+    for i in range(150):
         agent.step_batch()
-        got = agent.collect_examples(1, l_pos=24, l_neg=24)
-        if got > 20000:
-            break
+        agent.collect_examples(1, l_pos=24, l_neg=24)          # device-side trigger: no host round trip
+        if i % 10 == 9:
+            got = agent.examples_held(1)
+            if got > 20000:
+                break
     assert got > 2000, "random exploration never reached the goal"
     acc = agent.create_option(1)
     assert acc > 0.7      # random-walk positives and negatives overlap in space; the fit still separates them
-    xy, lab = agent._examples[1]
+    xy, lab = agent.examples(1)
     tx, ty, _ = agent.map.target
     d = torch.hypot(xy[:, 0] - tx, xy[:, 1] - ty)
     assert float(d[lab == 1].mean()) < float(d[lab == 0].mean())       # positives sit nearer the goal
@@ -190,4 +308,5 @@ def test_checkpoint_resume_continues_bit_identically(tmp_path):
     assert torch.equal(a.W, b.W) and a.t == b.t
     for ta, tb in zip(a.trace, b.trace):
         assert torch.equal(ta, tb)
-    assert torch.equal(a._examples[2][0], b._examples[2][0]) and torch.equal(a._examples[2][1], b._examples[2][1])
+    assert a.examples_held(2) == b.examples_held(2) > 0
+    assert torch.equal(a.examples(2)[0], b.examples(2)[0]) and torch.equal(a.examples(2)[1], b.examples(2)[1])
