@@ -156,6 +156,101 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_eval(const float *W /*[5][36]
     if (TIMING && lane == 0) cyc[blockIdx.x * WAVES + wave] = __builtin_amdgcn_s_memtime() - t0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// variant: W staged in LDS in A-operand order ([tile][k-block group of 4][lane][4] + [tile][lane] for kb = 8), A operands
+// streamed per MFMA; <= 128 VGPRs so that 4 waves share a SIMD (8-wave workgroups, two per CU)
+constexpr int WAVES2 = 8;
+template <bool TIMING>
+__global__ __launch_bounds__(WAVES2 * 64, 4) void k_eval_lds(const float *W, const float2 *Z1, int n_items, float *Q, int reps,
+                                                            unsigned long long *cyc) {
+    __shared__ __attribute__((aligned(16))) float s_w[12 * 9 * 64];
+    __shared__ __attribute__((aligned(16))) float s_tab[WAVES2][TAB_FLOATS];
+    __shared__ float2 s_z1[WAVES2][8 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    float *cdk = s_tab[wave], *abq = s_tab[wave] + 36 * 16;
+    // stage: entry (t, kb, lane) at ((t*3 + kb/4)*64 + lane)*4 + kb%4 for kb < 8, and 12*2*64*4 + (t*64 + lane) for kb = 8
+    for (int i = tid; i < 12 * 9 * 64; i += WAVES2 * 64) {
+        const int l = i & 63, kb = (i >> 6) % 9, t = (i >> 6) / 9;
+        const int row = 16 * t + (l & 15), gg = l >> 4;
+        const float v = row < 180 ? W[row * 36 + 9 * gg + kb] : 0.0f;
+        if (kb < 8) s_w[((t * 2 + (kb >> 2)) * 64 + l) * 4 + (kb & 3)] = v;
+        else s_w[12 * 2 * 64 * 4 + t * 64 + l] = v;
+    }
+    __syncthreads();
+    const int nblk = (n_items + 7) / 8;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int cb = blockIdx.x * WAVES2 + wave; cb < nblk; cb += gridDim.x * WAVES2) {
+            if (lane < 32) {
+                const int it = cb * 8 + (lane >> 2);
+                s_z1[wave][lane] = it < n_items ? Z1[it * 4 + (lane & 3)] : make_float2(1.0f, 0.0f);
+            }
+            wave_lds_sync();
+            build_tables(s_z1[wave], cdk, abq, lane);
+            wave_lds_sync();
+            float B[9];
+#pragma unroll
+            for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[64 * kb + lane];
+            f4 acc[12];
+#pragma unroll
+            for (int t = 0; t < 12; ++t) acc[t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const f4 a0 = *reinterpret_cast<const f4 *>(s_w + ((t * 2 + 0) * 64 + lane) * 4);
+                const f4 a1 = *reinterpret_cast<const f4 *>(s_w + ((t * 2 + 1) * 64 + lane) * 4);
+                const float a8 = s_w[12 * 2 * 64 * 4 + t * 64 + lane];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], acc[t], 0, 0, 0);
+            }
+            float q[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const int Ct = (16 * t) % 36, At = (16 * t) / 36;
+                const bool wrap = Ct + 4 * g >= 36;
+                const int c0 = Ct + 4 * g - (wrap ? 36 : 0);
+                const f4 ab = *reinterpret_cast<const f4 *>(abq + n * 36 + c0);
+                const bool mixed = Ct + 12 >= 36;
+                if (!mixed) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) q[At] = fmaf(acc[t][v], ab[v], q[At]);
+                } else {
+                    float x = wrap ? q[At + 1] : q[At];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) x = fmaf(acc[t][v], ab[v], x);
+                    q[At] = wrap ? q[At] : x;
+                    q[At + 1] = wrap ? x : q[At + 1];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) q[a] = q[a] + swz_xor4(q[a]);
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(q[a]), __float_as_uint(q[a]), false, false);
+                q[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[a]), __float_as_uint(q[a]), false, false);
+                q[a] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+            if (g == 0 && !(n & 4)) {
+                const int it = cb * 8 + (n >> 3) * 4 + (n & 3);
+                if (it < n_items) {
+#pragma unroll
+                    for (int a = 0; a < 5; ++a) Q[it * 5 + a] = q[a];
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+    if (TIMING && lane == 0) cyc[blockIdx.x * WAVES2 + wave] = __builtin_amdgcn_s_memtime() - t0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 struct cf { float re, im; };
 static cf h_cmul(cf a, cf b) { return {fmaf(-a.im, b.im, a.re * b.re), fmaf(a.re, b.im, a.im * b.re)}; }
@@ -243,6 +338,44 @@ int main() {
         cpu_q(W.data(), &Z[(n_items - 1) * 4], q);
         for (int a = 0; a < 5; ++a) { bad += memcmp(&q[a], &Qg[(size_t)(n_items - 1) * 5 + a], 4) != 0; ++checked; }
         printf("(2) evaluation loop vs scalar model: %d of %d Q values differ (sample Q = %g gpu %g)\n", bad, checked, q[0], Qg[(size_t)(n_items - 1) * 5]);
+    }
+    // ---- (2b) the LDS-streamed variant against the same model
+    CHECK(hipMemset(dQ, 0xff, (size_t)n_items * 5 * 4));
+    hipLaunchKernelGGL(k_eval_lds<false>, dim3(512), dim3(WAVES2 * 64), 0, 0, dW, dZ, n_items, dQ, 1, dcyc);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(Qg.data(), dQ, Qg.size() * 4, hipMemcpyDeviceToHost));
+    {
+        int bad = 0, checked = 0;
+        for (int it = 0; it < n_items; it += 37) {
+            float q[5];
+            cpu_q(W.data(), &Z[it * 4], q);
+            for (int a = 0; a < 5; ++a) { bad += memcmp(&q[a], &Qg[(size_t)it * 5 + a], 4) != 0; ++checked; }
+        }
+        printf("(2b) A operands streamed from LDS, 4 waves/SIMD: %d of %d Q values differ\n", bad, checked);
+    }
+    {
+        const int grid = 512, reps = 8;
+        const int items = grid * WAVES2 * 8 * 2;             // 2 column blocks per wave per rep
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_eval_lds<true>, dim3(grid), dim3(WAVES2 * 64), 0, 0, dW, dZ, items, dQ, reps, dcyc);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_eval_lds<true>, dim3(grid), dim3(WAVES2 * 64), 0, 0, dW, dZ, items, dQ, reps, dcyc);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0.0f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> cyc(grid * WAVES2);
+        CHECK(hipMemcpy(cyc.data(), dcyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (auto c : cyc) sum += (double)c;
+        const double per_blk = sum / cyc.size() / (reps * 2);
+        const double mfma = (double)items / 8 * reps * 108;
+        printf("(3b) LDS-streamed A, 2 x 8-wave workgroups/CU (4 waves/SIMD): %.0f cycles per 8-item block per wave, wall %.3f ms, "
+               "%.1f us per 65536+48000 items, MFMA pipe %.0f %% of 2.4 GHz peak\n",
+               per_blk, ms, ms * 1e3 * (65536.0 + 48000.0) / ((double)items * reps),
+               100.0 * mfma * 32.0 / (1024.0 * 2.4e9 * ms * 1e-3));
     }
     // ---- (3) timing
     for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu) {
