@@ -11,7 +11,7 @@ namespace scg {
 constexpr int NACT = 5;
 constexpr int NF = 1296;
 constexpr int BLOCK_ENVS = 128;               // SPEC §5 geometry: envs per block = per workgroup
-constexpr int WAVES = 4;                      // wavefronts per workgroup
+constexpr int WAVES = 8;                      // wavefronts per workgroup (two workgroups per CU: four waves per SIMD)
 constexpr int LIST_WAVES = BLOCK_ENVS / 64;   // waves that ballot the workgroup's env flags
 constexpr int THREADS = WAVES * 64;
 constexpr int MAX_EDGES = 256;

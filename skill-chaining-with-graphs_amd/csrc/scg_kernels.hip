@@ -31,21 +31,22 @@ using namespace scg;
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// LDS map of the step kernel (bytes)
-constexpr int OFF_EDGES = 0;                                   // float[256][8]
-constexpr int OFF_S = OFF_EDGES + MAX_EDGES * 32;              // float s[4][128], sn[4][128]
-constexpr int OFF_RC = OFF_S + 8 * BLOCK_ENVS * 4;             // float r0,c0,ro,co (per env), rk,ck (per env, this pass) [128]
+// LDS map of the step kernel (bytes). 8 wavefronts per workgroup, two workgroups per CU (80 KB each).
+constexpr int OFF_RC = 0;                                      // float r0,c0,ro,co (per env), rk,ck (per env, this pass) [128]
 constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia [128]
 constexpr int OFF_Z1 = OFF_INT + 5 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
-// region W: W_k staged in A-operand order (12 tiles x 9 k-blocks x 64 lanes), read once per wave per pass
-// region R, used by one phase at a time (R reaches back over region W, which is dead once the A operands are in registers):
-//   E, U1 : per wave CDk[36][16] + ABq[16][36] floats (4 x 4608 B), behind region W
-//   U2    : PT[36][US], CDT[36][US] (one chunk of 64 padded slots = 128 K-steps), from the start of region W
+// region R, used by one phase at a time:
+//   P, Z  : s[4][128], sn[4][128] (the envs' states) and the edge table [256][8]
+//   E, U1 : W_k staged in A-operand order (12 row tiles x 9 k-blocks x 64 lanes) + per wave CDk[36][16] + ABq[16][36]
+//   U2    : PT[36][US], CDT[36][US] (one chunk of 64 padded slots = 128 K-steps)
 constexpr int W_FLOATS = 12 * 9 * 64;
+constexpr int W_TAIL = 12 * 2 * 64 * 4;                        // k-block 8 of every tile sits behind the two float4 groups
 constexpr int E_TAB_FLOATS = 36 * 16 + 16 * 36;
 constexpr int US = 132;                                        // row stride of the chunk tables (floats)
-constexpr int R_TAB = W_FLOATS;                                // private tables start behind region W
-constexpr int R_FLOATS = (W_FLOATS + WAVES * E_TAB_FLOATS) > 2 * 36 * US ? (W_FLOATS + WAVES * E_TAB_FLOATS) : 2 * 36 * US;
+constexpr int R_TAB = W_FLOATS;                                // private tables start behind the staged W_k
+constexpr int R_S = 0, R_EDGES = 8 * BLOCK_ENVS;               // phase P / Z layout (floats)
+constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+constexpr int R_FLOATS = cmax3(W_FLOATS + WAVES * E_TAB_FLOATS, 2 * 36 * US, R_EDGES + MAX_EDGES * 8);
 constexpr int OFF_R = OFF_Z1 + BLOCK_ENVS * 2 * 4 * 8;
 constexpr int OFF_ELIST = OFF_R + R_FLOATS * 4;                // uint16 eval list[128]
 constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[128] (5 action runs)
@@ -61,7 +62,7 @@ constexpr int LDS_BYTES = OFF_STAMP + 128;
 constexpr int LDS_BYTES = OFF_MISC + 128;
 #endif
 static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
-static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0, "LDS alignment");
+static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0 && (R_EDGES * 4) % 16 == 0, "LDS alignment");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
@@ -191,10 +192,10 @@ __device__ __forceinline__ void item_tree_sum(float (&q)[M]) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
+__global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_edges = reinterpret_cast<float *>(smem + OFF_EDGES);
-    float *s_s = reinterpret_cast<float *>(smem + OFF_S);              // [8][128]: s then sn
+    float *s_s = reinterpret_cast<float *>(smem + OFF_R) + R_S;        // [8][128]: s then sn   (region R, phases P and Z)
+    float *s_edges = reinterpret_cast<float *>(smem + OFF_R) + R_EDGES;  // [n_edges][8]        (region R, phase P)
     float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
     float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
     float *s_rk = s_co + BLOCK_ENVS, *s_ck = s_rk + BLOCK_ENVS;       // reward / continuation of the pass's value function
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     }
 
     // ------------------------------------------------------------------ phase P
-    if (lane < 32) {                                  // 4 waves x 32 lanes (64-lane waves measured slower: 22.1k vs 18.8k
+    if (wave < BLOCK_ENVS / 32 && lane < 32) {        // 4 waves x 32 lanes (64-lane waves measured slower: 22.1k vs 18.8k
         const int i = wave * 32 + lane;               // cycles for the physics — more divergence per wave)
         const int e = (MODE == MODE_FUSED && A.perm && i < nb) ? A.perm[e0 + i] : e0 + i;
         s_env[i] = e;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s and s_next
     {
         const int i = tid & (BLOCK_ENVS - 1), sg = tid / BLOCK_ENVS;
-        if (i < nb && (MODE != MODE_QVAL || sg == 1)) {
+        if (sg < 2 && i < nb && (MODE != MODE_QVAL || sg == 1)) {
             const float *st = s_s + sg * 4 * BLOCK_ENVS;
             const float sv0 = st[i], sv1 = st[BLOCK_ENVS + i];
             const float sv2 = fmaf(st[2 * BLOCK_ENVS + i], 0.25f, 0.5f), sv3 = fmaf(st[3 * BLOCK_ENVS + i], 0.25f, 0.5f);
@@ -445,7 +446,8 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             }
         }
         // W_k -> LDS in A-operand order while the counts settle: W_k is a 180 x 36 matrix (row = 36 a + c12) cut into
-        // 12 row tiles; entry (tile t, k-block kb, lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 are zero.
+        // 12 row tiles; entry (tile t, k-block kb, lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 are zero. Per tile
+        // and lane the k-blocks 0..3 and 4..7 form two float4 (one ds_read_b128 feeds four MFMAs), k-block 8 sits apart.
         // One coalesced read per workgroup instead of one 27 KB gather per wave (every workgroup of the chip reads
         // the same 26 KB at the same moment: the L2 channels holding it were the bottleneck).
         const float *Wk = A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF);
@@ -454,17 +456,19 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) {
                 const float4 w = Wk4[f4];
                 const int row = f4 / 9, c0 = 4 * (f4 - 9 * row);
-                const int base = ((row >> 4) * 9) * 64 + (row & 15);
+                const int t = row >> 4, nn = row & 15;
                 const float wv[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = c0 + e, gg = (c * 57) >> 9, kb = c - 9 * gg;      // c / 9, c % 9 for c < 36
-                    s_W[base + kb * 64 + gg * 16] = wv[e];
+                    const int ln = gg * 16 + nn;
+                    s_W[kb < 8 ? ((t * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + t * 64 + ln] = wv[e];
                 }
             }
             for (int z = tid; z < 9 * 4 * 12; z += THREADS) {                        // tile 11, rows 180..191
                 const int kb = z / 48, r = z - 48 * kb, gg = r / 12, nn = 4 + (r - 12 * gg);
-                s_W[(11 * 9 + kb) * 64 + gg * 16 + nn] = 0.0f;
+                const int ln = gg * 16 + nn;
+                s_W[kb < 8 ? ((11 * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + 11 * 64 + ln] = 0.0f;
             }
         }
         block_lds_sync();
@@ -507,20 +511,18 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
         if (n_ev + nupd == 0) continue;
 
         // column blocks of this pass: nqe of the eval list, then per action run ceil(run_len / 8) of the update list;
-        // block index i goes to wave i & 3
+        // block index i goes to wave i & 7
         const int nqe = (n_ev + 7) >> 3;
         int uq0[NACT + 1];
         uq0[0] = nqe;
 #pragma unroll
         for (int a = 0; a < NACT; ++a) uq0[a + 1] = uq0[a] + ((run_len[a] + 7) >> 3);
         if (wave < uq0[NACT]) {
-            float Wr[12][9];
-#pragma unroll
-            for (int t = 0; t < 12; ++t) {
-#pragma unroll
-                for (int kb = 0; kb < 9; ++kb) Wr[t][kb] = s_W[(t * 9 + kb) * 64 + lane];
-            }
-            SCG_STAMP(k == 0 ? 2 : 9);    // A operands in registers
+            // A operands come from the staged W_k, per row tile two ds_read_b128 (k-blocks 0..3, 4..7) and one ds_read_b32
+            // (k-block 8): the kernel stays below 128 VGPRs, four waves share a SIMD, and while one wave builds tables or
+            // folds its accumulators another one keeps the matrix pipe busy
+            const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane;
+            const float *w8 = s_W + W_TAIL + lane;
             // ---- E: Q_k(s_next, .) of the eval list, one 8-item column block per wave-iteration (SPEC §3.1)
             for (int cb = wave; cb < nqe; cb += WAVES) {
                 build_block(s_elist, 8 * cb, min(8, n_ev - 8 * cb), 1);
@@ -530,12 +532,15 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
                 f4v acc[12];
 #pragma unroll
-                for (int t = 0; t < 12; ++t) acc[t] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+                for (int t = 0; t < 12; ++t) {
+                    const f4v a0 = w4[(t * 2) * 64], a1 = w4[(t * 2 + 1) * 64];
+                    const float a8 = w8[t * 64];
+                    f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int kb = 0; kb < 9; ++kb) {
+                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < 12; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[t][kb], B[kb], acc[t], 0, 0, 0);
+                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
                 }
                 // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
                 float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -581,47 +586,43 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             // ---- U1: Q_k(s, a_t) of the update items, per action run, 8 items per wave-iteration: the same contraction
             // on the 3 row tiles that hold action a's rows -> s_qsa[list position]
             if (MODE != MODE_QVAL && nupd > 0) {
-                auto run_u1 = [&](auto aa_c) {
-                    constexpr int AA = decltype(aa_c)::value;
-                    constexpr int T0 = (36 * AA) / 16;
-                    const int cnt = run_len[AA];
-                    const uint16_t *lst = s_ulist + run_off[AA];
-                    for (int cb = ((wave - uq0[AA]) & 3); 8 * cb < cnt; cb += WAVES) {
+#pragma unroll 1
+                for (int a = 0; a < NACT; ++a) {
+                    const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
+                    const int cnt = run_len[a];
+                    const uint16_t *lst = s_ulist + run_off[a];
+                    for (int cb = ((wave - uq0[a]) & (WAVES - 1)); 8 * cb < cnt; cb += WAVES) {
                         build_block(lst, 8 * cb, min(8, cnt - 8 * cb), 0);
                         wave_lds_sync();
                         float B[9];
 #pragma unroll
                         for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-                        f4v acc[3];
-#pragma unroll
-                        for (int tt = 0; tt < 3; ++tt) acc[tt] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int kb = 0; kb < 9; ++kb) {
-#pragma unroll
-                            for (int tt = 0; tt < 3; ++tt)
-                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[T0 + tt][kb], B[kb], acc[tt], 0, 0, 0);
-                        }
                         float qs = 0.0f;
 #pragma unroll
                         for (int tt = 0; tt < 3; ++tt) {
-                            constexpr int dummy_ = 0; (void)dummy_;
-                            const int r0 = 16 * (T0 + tt) + 4 * g - 36 * AA;       // c12 of the lane's first row, if in [0, 36)
+                            const int t = t0 + tt;
+                            const f4v a0 = w4[(t * 2) * 64], a1 = w4[(t * 2 + 1) * 64];
+                            const float a8 = w8[t * 64];
+                            f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
+#pragma unroll
+                            for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
+                            const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
                             const bool in = r0 >= 0 && r0 < 36;
                             const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + (in ? r0 : 0));
                             float xq = qs;
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) xq = fmaf(acc[tt][v], ab4[v], xq);
+                            for (int v = 0; v < 4; ++v) xq = fmaf(c[v], ab4[v], xq);
                             qs = in ? xq : qs;
                         }
                         float qo[1] = {qs};
                         item_tree_sum<1>(qo);
-                        if (out_lane && 8 * cb + ocol_item < cnt) s_qsa[run_off[AA] + 8 * cb + ocol_item] = qo[0];
+                        if (out_lane && 8 * cb + ocol_item < cnt) s_qsa[run_off[a] + 8 * cb + ocol_item] = qo[0];
                         wave_lds_sync();
                     }
-                };
-                run_u1(std::integral_constant<int, 0>{}); run_u1(std::integral_constant<int, 1>{});
-                run_u1(std::integral_constant<int, 2>{}); run_u1(std::integral_constant<int, 3>{});
-                run_u1(std::integral_constant<int, 4>{});
+                }
             }
         }
         if (MODE == MODE_QVAL || nupd == 0) continue;
@@ -631,30 +632,28 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
 
         // ---- U2: the block partial (SPEC §5). Padded slots: every action run is padded with null items to a multiple of
         // 4, run a occupying slots [off4[a], off4[a] + len4[a]). Chunks of 64 slots (128 K-steps, kap = 2 slot + part):
-        //   build  PT[c12][kap] = delta * ABsel, CDT[c34][kap] = CD  (null items: +0), all four waves
+        //   build  PT[c12][kap] = delta * ABsel, CDT[c34][kap] = CD  (null items: +0); wave w owns slots 8 w .. 8 w + 7
         //   MFMA   G[a] += PT x CDT^T, groups of 4 items: one MFMA over their real parts, one over the imaginary parts;
-        //          the 9 output tiles of action a are dealt to the waves (tile q -> wave (q - a) & 3), accumulators stay in
-        //          registers for the whole pass and go straight to the block's slab
+        //          the 9 output tiles of action a are dealt to the 8 waves (tile q -> wave (q + a) & 7, so wave a holds two),
+        //          accumulators stay in registers for the whole pass and go straight to the block's slab
         int off4[NACT + 1];
         off4[0] = 0;
 #pragma unroll
         for (int a = 0; a < NACT; ++a) off4[a + 1] = off4[a] + ((run_len[a] + 3) & ~3);
         int wave_u = wave;
         asm volatile("" : "+s"(wave_u));                    // keeps the per-(wave, action) tile geometry inside the pass
-        f4v accU[NACT][3];
+        f4v accU[NACT][2];
 #pragma unroll
         for (int a = 0; a < NACT; ++a) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) accU[a][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int s = 0; s < 2; ++s) accU[a][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
         }
         float *ptab = s_R, *ctab = s_R + 36 * US;
         for (int ch0 = 0; ch0 < off4[NACT]; ch0 += 64) {
             if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
             SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
-            // build: wave w, round r owns chunk slots 16 w + 8 r + bi
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int slot = 16 * wave + 8 * r + bi, ps = ch0 + slot;
+            {
+                const int slot = 8 * wave + bi, ps = ch0 + slot;
                 if (cp < 6 && ps < off4[NACT]) {
                     int a_ = 0;
 #pragma unroll
@@ -692,27 +691,17 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                 constexpr int AA = decltype(aa_c)::value;
                 const int lo = max(off4[AA], ch0), hi = min(off4[AA + 1], ch0 + 64);      // the run's slots in this chunk
                 if (lo >= hi) return;
-                const int wq = (wave_u + AA) & 3;                // this wave's tiles: wq, wq + 4 (, 8 when wq == 0)
-                const float *pa[3], *pb[3];
+                const bool two = wave_u == AA;                   // this wave's tiles: (wave - AA) & 7, and tile 8 on wave AA
+                const float *pa[2], *pb[2];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int q = min(wq + 4 * s, 8);
+                for (int s = 0; s < 2; ++s) {
+                    const int q = s == 0 ? ((wave_u - AA) & 7) : 8;
                     const int mi = (q * 11) >> 5, ni = q - 3 * mi;             // q / 3, q % 3
                     pa[s] = ptab + min(16 * mi + n16, 35) * US + 2 * g + 2 * (lo - ch0);
                     pb[s] = ctab + min(16 * ni + n16, 35) * US + 2 * g + 2 * (lo - ch0);
                 }
                 const int ngrp = (hi - lo) >> 2;
-                if (wq == 0) {
-                    for (int gi = 0; gi < ngrp; ++gi) {
-                        float2 a2[3], b2[3];
-#pragma unroll
-                        for (int s = 0; s < 3; ++s) { a2[s] = *reinterpret_cast<const float2 *>(pa[s] + 8 * gi); b2[s] = *reinterpret_cast<const float2 *>(pb[s] + 8 * gi); }
-#pragma unroll
-                        for (int s = 0; s < 3; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].x, b2[s].x, accU[AA][s], 0, 0, 0);
-#pragma unroll
-                        for (int s = 0; s < 3; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].y, b2[s].y, accU[AA][s], 0, 0, 0);
-                    }
-                } else {
+                if (two) {
                     for (int gi = 0; gi < ngrp; ++gi) {
                         float2 a2[2], b2[2];
 #pragma unroll
@@ -721,6 +710,12 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
                         for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].x, b2[s].x, accU[AA][s], 0, 0, 0);
 #pragma unroll
                         for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].y, b2[s].y, accU[AA][s], 0, 0, 0);
+                    }
+                } else {
+                    for (int gi = 0; gi < ngrp; ++gi) {
+                        const float2 a2 = *reinterpret_cast<const float2 *>(pa[0] + 8 * gi), b2 = *reinterpret_cast<const float2 *>(pb[0] + 8 * gi);
+                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, accU[AA][0], 0, 0, 0);
+                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, accU[AA][0], 0, 0, 0);
                     }
                 }
             };
@@ -735,11 +730,10 @@ __global__ __launch_bounds__(THREADS, 2) void td_kernel(const StepArgs A) {
             float *slab_lane = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF + (4 * g) * 36 + n16;
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
-                const int wq = (wave_u + a) & 3;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int q = wq + 4 * s;
-                    if (s < 2 || wq == 0) {
+                for (int s = 0; s < 2; ++s) {
+                    const int q = s == 0 ? ((wave_u - a) & 7) : 8;
+                    if (s == 0 || wave_u == a) {
                         const int mi = (q * 11) >> 5, ni = q - 3 * mi;         // wave-uniform
                         const bool okl = (mi < 2 || g == 0) && (ni < 2 || n16 < 4);
                         float *dst = slab_lane + a * NF + (16 * mi) * 36 + 16 * ni;
