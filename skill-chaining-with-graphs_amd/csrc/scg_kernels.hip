@@ -445,6 +445,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 s_misc[wave * 8 + lane] = __popcll(mine);
             }
         }
+        SCG_STAMP(23);                                       // (diagnostic) flags + ballots
         // W_k -> LDS in A-operand order while the counts settle: W_k is a 180 x 36 matrix (row = 36 a + c12) cut into
         // 12 row tiles; entry (tile t, k-block kb, lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 are zero. Per tile
         // and lane the k-blocks 0..3 and 4..7 form two float4 (one ds_read_b128 feeds four MFMAs), k-block 8 sits apart.
@@ -471,7 +472,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 s_W[kb < 8 ? ((11 * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + 11 * 64 + ln] = 0.0f;
             }
         }
+        SCG_STAMP(24);                                       // (diagnostic) W staging
         block_lds_sync();
+        SCG_STAMP(25);                                       // (diagnostic) wait at the barrier behind the staging
         int n_ev = 0, run_len[NACT], run_off[NACT];
         {
             int se = 0;
