@@ -44,7 +44,8 @@ constexpr int W_TAIL = 12 * 2 * 64 * 4;                        // k-block 8 of e
 constexpr int E_TAB_FLOATS = 36 * 16 + 16 * 36;
 constexpr int US = 132;                                        // row stride of the chunk tables (floats)
 constexpr int R_TAB = W_FLOATS;                                // private tables start behind the staged W_k
-constexpr int R_S = 0, R_EDGES = 8 * BLOCK_ENVS;               // phase P / Z layout (floats)
+constexpr int R_S = R_TAB, R_EDGES = R_TAB + 8 * BLOCK_ENVS;   // phases P / Z: inside the table area of waves 0..3 (the helper
+                                                               // waves 4..7 use region W and their own tables meanwhile)
 constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 constexpr int R_FLOATS = cmax3(W_FLOATS + WAVES * E_TAB_FLOATS, 2 * 36 * US, R_EDGES + MAX_EDGES * 8);
 constexpr int OFF_R = OFF_Z1 + BLOCK_ENVS * 2 * 4 * 8;
@@ -63,6 +64,7 @@ constexpr int LDS_BYTES = OFF_MISC + 128;
 #endif
 static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
 static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0 && (R_EDGES * 4) % 16 == 0, "LDS alignment");
+static_assert(8 * BLOCK_ENVS + MAX_EDGES * 8 <= 4 * E_TAB_FLOATS, "states + edges fit the table area of waves 0..3");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
@@ -227,10 +229,129 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 
     if (MODE == MODE_FUSED) {
         for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
-        if (tid == 0) { s_misc[31] = 1; s_misc[30] = 1; }  // bit k: some env here has an item / an UPDATE item for VF k
+        if (tid == 0) { s_misc[31] = 1; s_misc[30] = 1; s_misc[29] = 0; s_misc[28] = 0; }  // [31]/[30] bit k: some env here has an item /
+                                                           // an UPDATE item for VF k; [29]/[28]: hand-off counters
         if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
         block_lds_sync();
     }
+
+    // Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
+    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
+    // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
+    // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
+    // imaginary-part column at 8 h + 4 + i.
+    const int n16 = lane & 15, g = lane >> 4;
+    const int bi = lane & 7, cp = lane >> 3;
+    const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
+    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
+    const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
+    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
+    const float *ab_lane = abq + n16 * 36 + 4 * g;
+
+    // private tables of one 8-item column block: items lst[i0 .. i0 + cnt) (a short block repeats its last item),
+    // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
+    auto build_block = [&](const uint16_t *lst, int i0, int cnt, int sg) {
+        if (cp < 6) {
+            const int it = lst[i0 + min(bi, cnt - 1)];
+            float2 ab[6], cd[6];
+            item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                abq[bcol * 36 + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * 36 + 6 * c + cp] = -ab[c].y;
+                cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
+            }
+        }
+    };
+
+    // A operands come from the staged W_k, per row tile two ds_read_b128 (k-blocks 0..3, 4..7) and one ds_read_b32
+    // (k-block 8): the kernel stays below 128 VGPRs, four waves share a SIMD, and while one wave builds tables or
+    // folds its accumulators another one keeps the matrix pipe busy
+    const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane;
+    const float *w8 = s_W + W_TAIL + lane;
+
+    // U1: Q_k(s, a_t) of the update items, per action run, 8 items per wave-iteration: the contraction of E on the 3 row
+    // tiles that hold action a's rows -> s_qsa[list position]. The column blocks of all runs are dealt to `nw` waves.
+    auto run_u1 = [&](int wv, int nw, const int (&rl)[NACT], const int (&ro)[NACT]) {
+        int base = 0;
+#pragma unroll 1
+        for (int a = 0; a < NACT; ++a) {
+            const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
+            const int cnt = rl[a];
+            const uint16_t *lst = s_ulist + ro[a];
+            for (int cb = ((wv - base) & (nw - 1)); 8 * cb < cnt; cb += nw) {
+                build_block(lst, 8 * cb, min(8, cnt - 8 * cb), 0);
+                wave_lds_sync();
+                float B[9];
+#pragma unroll
+                for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+                float qs = 0.0f;
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) {
+                    const int t = t0 + tt;
+                    const f4v a0 = w4[(t * 2) * 64], a1 = w4[(t * 2 + 1) * 64];
+                    const float a8 = w8[t * 64];
+                    f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
+                    const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
+                    const bool in = r0 >= 0 && r0 < 36;
+                    const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + (in ? r0 : 0));
+                    float xq = qs;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xq = fmaf(c[v], ab4[v], xq);
+                    qs = in ? xq : qs;
+                }
+                float qo[1] = {qs};
+                item_tree_sum<1>(qo);
+                if (out_lane && 8 * cb + ocol_item < cnt) s_qsa[ro[a] + 8 * cb + ocol_item] = qo[0];
+                wave_lds_sync();
+            }
+            base += (cnt + 7) >> 3;
+        }
+    };
+    // W_k -> region W in A-operand order (12 row tiles of the 180 x 36 matrix; entry (tile t, k-block kb, lane (n16, g)) =
+    // W[16 t + n16][9 g + kb], rows >= 180 zero; per tile and lane the k-blocks 0..3 and 4..7 form two float4 — one
+    // ds_read_b128 feeds four MFMAs — and k-block 8 sits apart), by `nth` threads with index `ht`. One coalesced read per
+    // workgroup instead of a 27 KB gather per wave: every workgroup of the chip wants the same 26 KB at the same moment,
+    // and the L2 channels holding them were the bottleneck.
+    auto stage_w = [&](const float *Wk, int ht, int nth) {
+        const float4 *Wk4 = reinterpret_cast<const float4 *>(Wk);
+        for (int f4 = ht; f4 < NACT * NF / 4; f4 += nth) {
+            const float4 w = Wk4[f4];
+            const int row = f4 / 9, c0 = 4 * (f4 - 9 * row);
+            const int t = row >> 4, nn = row & 15;
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e, gg = (c * 57) >> 9, kb = c - 9 * gg;      // c / 9, c % 9 for c < 36
+                const int ln = gg * 16 + nn;
+                s_W[kb < 8 ? ((t * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + t * 64 + ln] = wv[e];
+            }
+        }
+        for (int z = ht; z < 9 * 4 * 12; z += nth) {                             // tile 11, rows 180..191
+            const int kb = z / 48, r = z - 48 * kb, gg = r / 12, nn = 4 + (r - 12 * gg);
+            const int ln = gg * 16 + nn;
+            s_W[kb < 8 ? ((11 * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + 11 * 64 + ln] = 0.0f;
+        }
+    };
+    // counters in LDS for hand-offs between SUBSETS of the workgroup's waves (s_barrier takes all eight): a producer
+    // publishes with lds_arrive, a consumer polls with lds_await. Every awaited count is reached by waves that never
+    // wait on the waiter, so the polls terminate.
+    auto lds_arrive = [&](int *ctr, int amount) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == __builtin_ctzll(__ballot(true))) atomicAdd(ctr, amount);
+    };
+    auto lds_await = [&](int *ctr, int want) {
+        for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want && spins < (1 << 20); ++spins)
+            __builtin_amdgcn_s_sleep(2);                      // (the bound only guards the GPU against a logic error)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // With learning on, waves 4..7 ("helpers") are idle during phase P (one lane per env on 4 x 32 lanes, latency-bound):
+    // they stage W_0, take Z_d^1 of the entry states, build the root's update list and run U1 of the root pass under it.
+    const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
 
     // ------------------------------------------------------------------ phase P
     if (wave < BLOCK_ENVS / 32 && lane < 32) {        // 4 waves x 32 lanes (64-lane waves measured slower: 22.1k vs 18.8k
@@ -259,6 +380,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 const int ep0 = A.ep_steps[e], o = A.option_id[e], osteps = A.opt_steps[e];   // early: latency hides under the physics
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
+                s_a[i] = (uint8_t)a;
+                if (helpers) lds_arrive(&s_misc[29], __popcll(__ballot(true)));      // state and action of these envs are out
                 // physics (SPEC §1.3)
                 bool goal;
                 SCG_STAMP(17);                                        // P: state gathers
@@ -355,6 +478,41 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         } else {
             s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
         }
+    } else if (helpers && wave >= BLOCK_ENVS / 32) {
+        const int ht = tid - BLOCK_ENVS / 32 * 64, hw = wave - BLOCK_ENVS / 32;       // helper thread / wave index (256 threads, 4 waves)
+        stage_w(A.W, ht, THREADS - BLOCK_ENVS / 32 * 64);
+        lds_await(&s_misc[29], nb);                                                    // the P waves have published s and a
+        if (ht < nb) {                                                                 // Z_d^1 of the entry states
+            const float sv2 = fmaf(s_s[2 * BLOCK_ENVS + ht], 0.25f, 0.5f), sv3 = fmaf(s_s[3 * BLOCK_ENVS + ht], 0.25f, 0.5f);
+            const float2 za = sincospi_cs(s_s[ht]), zb = sincospi_cs(s_s[BLOCK_ENVS + ht]), zc = sincospi_cs(sv2), zd = sincospi_cs(sv3);
+            float4 *dst = reinterpret_cast<float4 *>(s_z1 + (ht * 2 + 0) * 4);
+            dst[0] = make_float4(za.x, za.y, zb.x, zb.y);
+            dst[1] = make_float4(zc.x, zc.y, zd.x, zd.y);
+        }
+        // the root's update list (every env, one run per action, block order inside a run): each helper wave derives the
+        // run geometry itself from two rounds of ballots; helper wave 0 writes the list
+        int rl[NACT], ro[NACT];
+        {
+            uint64_t m0[NACT], m1[NACT];
+            const int at0 = lane < nb ? s_a[lane] : -1, at1 = 64 + lane < nb ? s_a[64 + lane] : -1;
+            int off = 0;
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {
+                m0[a] = __ballot(at0 == a); m1[a] = __ballot(at1 == a);
+                rl[a] = __popcll(m0[a]) + __popcll(m1[a]); ro[a] = off; off += rl[a];
+            }
+            if (hw == 0) {
+                const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) {
+                    if (at0 == a) s_ulist[ro[a] + __popcll(m0[a] & below)] = (uint16_t)lane;
+                    if (at1 == a) s_ulist[ro[a] + __popcll(m0[a]) + __popcll(m1[a] & below)] = (uint16_t)(64 + lane);
+                }
+            }
+        }
+        lds_arrive(&s_misc[28], 1);
+        lds_await(&s_misc[28], WAVES - BLOCK_ENVS / 32);                               // W_0, Z(s) and the list are complete
+        run_u1(hw, WAVES - BLOCK_ENVS / 32, rl, ro);
     }
     block_lds_sync();
 
@@ -362,7 +520,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s and s_next
     {
         const int i = tid & (BLOCK_ENVS - 1), sg = tid / BLOCK_ENVS;
-        if (sg < 2 && i < nb && (MODE != MODE_QVAL || sg == 1)) {
+        if (sg < 2 && i < nb && (MODE != MODE_QVAL || sg == 1) && !(helpers && sg == 0)) {
             const float *st = s_s + sg * 4 * BLOCK_ENVS;
             const float sv0 = st[i], sv1 = st[BLOCK_ENVS + i];
             const float sv2 = fmaf(st[2 * BLOCK_ENVS + i], 0.25f, 0.5f), sv3 = fmaf(st[3 * BLOCK_ENVS + i], 0.25f, 0.5f);
@@ -374,34 +532,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     }
 
     // ------------------------------------------------------------------ phase TD (SPEC §3.1, §5) on the matrix pipe
-    // Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
-    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
-    // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
-    // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
-    // imaginary-part column at 8 h + 4 + i.
-    const int n16 = lane & 15, g = lane >> 4;
-    const int bi = lane & 7, cp = lane >> 3;
-    const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
-    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
-    const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
-    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
-    const float *ab_lane = abq + n16 * 36 + 4 * g;
-
-    // private tables of one 8-item column block: items lst[i0 .. i0 + cnt) (a short block repeats its last item),
-    // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
-    auto build_block = [&](const uint16_t *lst, int i0, int cnt, int sg) {
-        if (cp < 6) {
-            const int it = lst[i0 + min(bi, cnt - 1)];
-            float2 ab[6], cd[6];
-            item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                abq[bcol * 36 + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * 36 + 6 * c + cp] = -ab[c].y;
-                cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
-            }
-        }
-    };
-
     const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[31]) : ~0u;
     // value functions that only have envs ENTERING them here (evaluation-only: no update item, a handful of items — 1.6
     // such VFs with 3.5 items each per workgroup on the bench workload) skip the pass machinery: see the tail of the kernel
@@ -450,32 +580,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
         }
         SCG_STAMP(23);                                       // (diagnostic) flags + ballots
-        // W_k -> LDS in A-operand order while the counts settle: W_k is a 180 x 36 matrix (row = 36 a + c12) cut into
-        // 12 row tiles; entry (tile t, k-block kb, lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 are zero. Per tile
-        // and lane the k-blocks 0..3 and 4..7 form two float4 (one ds_read_b128 feeds four MFMAs), k-block 8 sits apart.
-        // One coalesced read per workgroup instead of one 27 KB gather per wave (every workgroup of the chip reads
-        // the same 26 KB at the same moment: the L2 channels holding it were the bottleneck).
         const float *Wk = A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF);
-        {
-            const float4 *Wk4 = reinterpret_cast<const float4 *>(Wk);
-            for (int f4 = tid; f4 < NACT * NF / 4; f4 += THREADS) {
-                const float4 w = Wk4[f4];
-                const int row = f4 / 9, c0 = 4 * (f4 - 9 * row);
-                const int t = row >> 4, nn = row & 15;
-                const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = c0 + e, gg = (c * 57) >> 9, kb = c - 9 * gg;      // c / 9, c % 9 for c < 36
-                    const int ln = gg * 16 + nn;
-                    s_W[kb < 8 ? ((t * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + t * 64 + ln] = wv[e];
-                }
-            }
-            for (int z = tid; z < 9 * 4 * 12; z += THREADS) {                        // tile 11, rows 180..191
-                const int kb = z / 48, r = z - 48 * kb, gg = r / 12, nn = 4 + (r - 12 * gg);
-                const int ln = gg * 16 + nn;
-                s_W[kb < 8 ? ((11 * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + 11 * 64 + ln] = 0.0f;
-            }
-        }
+        if (!(helpers && k == 0)) stage_w(Wk, tid, THREADS);   // (the helper waves staged W_0 under phase P)
         SCG_STAMP(24);                                       // (diagnostic) W staging
         block_lds_sync();
         SCG_STAMP(25);                                       // (diagnostic) wait at the barrier behind the staging
@@ -520,16 +626,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         // column blocks of this pass: nqe of the eval list, then per action run ceil(run_len / 8) of the update list;
         // block index i goes to wave i & 7
         const int nqe = (n_ev + 7) >> 3;
-        int uq0[NACT + 1];
-        uq0[0] = nqe;
-#pragma unroll
-        for (int a = 0; a < NACT; ++a) uq0[a + 1] = uq0[a] + ((run_len[a] + 7) >> 3);
-        if (wave < uq0[NACT]) {
-            // A operands come from the staged W_k, per row tile two ds_read_b128 (k-blocks 0..3, 4..7) and one ds_read_b32
-            // (k-block 8): the kernel stays below 128 VGPRs, four waves share a SIMD, and while one wave builds tables or
-            // folds its accumulators another one keeps the matrix pipe busy
-            const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane;
-            const float *w8 = s_W + W_TAIL + lane;
+        if (wave < nqe) {
             // ---- E: Q_k(s_next, .) of the eval list, one 8-item column block per wave-iteration (SPEC §3.1)
             for (int cb = wave; cb < nqe; cb += WAVES) {
                 build_block(s_elist, 8 * cb, min(8, n_ev - 8 * cb), 1);
@@ -589,49 +686,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 wave_lds_sync();
             }
-            SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
-            // ---- U1: Q_k(s, a_t) of the update items, per action run, 8 items per wave-iteration: the same contraction
-            // on the 3 row tiles that hold action a's rows -> s_qsa[list position]
-            if (MODE != MODE_QVAL && nupd > 0) {
-#pragma unroll 1
-                for (int a = 0; a < NACT; ++a) {
-                    const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
-                    const int cnt = run_len[a];
-                    const uint16_t *lst = s_ulist + run_off[a];
-                    for (int cb = ((wave - uq0[a]) & (WAVES - 1)); 8 * cb < cnt; cb += WAVES) {
-                        build_block(lst, 8 * cb, min(8, cnt - 8 * cb), 0);
-                        wave_lds_sync();
-                        float B[9];
-#pragma unroll
-                        for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-                        float qs = 0.0f;
-#pragma unroll
-                        for (int tt = 0; tt < 3; ++tt) {
-                            const int t = t0 + tt;
-                            const f4v a0 = w4[(t * 2) * 64], a1 = w4[(t * 2 + 1) * 64];
-                            const float a8 = w8[t * 64];
-                            f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                            for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
-#pragma unroll
-                            for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
-                            const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
-                            const bool in = r0 >= 0 && r0 < 36;
-                            const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + (in ? r0 : 0));
-                            float xq = qs;
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) xq = fmaf(c[v], ab4[v], xq);
-                            qs = in ? xq : qs;
-                        }
-                        float qo[1] = {qs};
-                        item_tree_sum<1>(qo);
-                        if (out_lane && 8 * cb + ocol_item < cnt) s_qsa[run_off[a] + 8 * cb + ocol_item] = qo[0];
-                        wave_lds_sync();
-                    }
-                }
-            }
         }
+        SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
+        // ---- U1 (the root's ran under phase P on the helper waves)
+        if (MODE != MODE_QVAL && nupd > 0 && !(helpers && k == 0)) run_u1(wave, WAVES, run_len, run_off);
         if (MODE == MODE_QVAL || nupd == 0) continue;
         SCG_STAMP(k == 0 ? 4 : 11);   // U1 (wave 0's share)
         block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
