@@ -68,9 +68,9 @@ except (OSError, ValueError):
 
 def measured_traffic(envs_per_gpu, n_options):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate passes; profiles/r01_traffic.json) — only when it was taken on this exact workload."""
+    WRITE_SIZE, separate passes; profiles/r02_traffic.json) — only when it was taken on this exact workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
         if w["envs_per_gpu"] == envs_per_gpu and w["n_options"] == n_options and w["map"] == MAP:
