@@ -1,21 +1,25 @@
 // scg_kernels.hip — gfx950 kernels + the C-ABI of include/scg_abi.h.
 //
 // One step-batch (SPEC §5) = td_kernel<FUSED> -> reduce_kernel (+ sort_hist / sort_scatter when no env order is
-// prepared). td_kernel: a workgroup = 4 wavefronts owns 128 consecutive positions of the option-sorted env order.
-//   phase P  (one lane per env)       act from qcache, Pinball physics (cell mask -> exact refine -> up to
-//                                     three candidate edges in registers), reset/bookkeeping, option logic
-//   phase Z  (one lane per env-state) Z_d^1 = sincospi of the four normalised state variables of s and s_next -> LDS
+// prepared). td_kernel: a workgroup = 8 wavefronts owns 128 consecutive positions of the option-sorted env order; two
+// workgroups per CU, <= 128 VGPRs, four waves per SIMD.
+//   phase P  (waves 0..3, one lane per env)  act from qcache, Pinball physics (cell mask -> exact refine -> up to three
+//            candidate edges in registers), reset/bookkeeping, option logic; MEANWHILE waves 4..7 stage W_0, take Z_d^1 of
+//            the entry states, build the root's update list and run U1 of the root pass
+//   phase Z  Z_d^1 = sincospi of the four normalised state variables of s_next -> LDS
 //   phase TD, value function by value function, on the matrix pipe (v_mfma_f32_16x16x4_f32 is bit for bit a k-ordered
 //            fmaf chain, so the CPU oracle reproduces every sum):
-//     E   Q_k(s_next, .) of 8 items per wave-iteration: T[(a,c12)][item re|im] = W_k (180 x 36, resident in 108
-//         VGPRs as A operands) x CD (36 x 16, from a per-wave LDS table) = 108 MFMAs, then per lane 48 fmas with the
-//         AB factors and a 3-stage butterfly (SPEC §3.1)
-//     U1  Q_k(s, a_t) per action run, 32 items at a time: the same contraction on the 3 row tiles of action a_t
+//     E   Q_k(s_next, .) of 8 items per wave-iteration: T[(a,c12)][item re|im] = W_k (180 x 36, staged in LDS in
+//         A-operand order, one ds_read_b128 per four MFMAs) x CD (36 x 16, from a per-wave LDS table) = 108 MFMAs, then
+//         per lane 48 fmas with the AB factors and a 3-stage butterfly (SPEC §3.1)
+//     U1  Q_k(s, a_t) per action run: the same contraction on the 3 row tiles of action a_t
 //     U2  the block partial G_b,k[a] (36 x 36) += P (36 x 2n, delta-scaled AB factors) x C^T (2n x 36, CD factors):
-//         9 output tiles per action dealt over the 4 waves, accumulators stay in registers for the whole pass and
+//         9 output tiles per action dealt over the 8 waves, accumulators stay in registers for the whole pass and
 //         go straight to the block's slab (no cross-wave reduction)
+//   tail     value functions that only have envs ENTERING them here: the same chains on the vector pipe, per wave
 //   reduce_kernel  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G; commit + next env order
-// Every sum has the pinned order of SPEC §3.1 / §5 (no atomics on data): the CPU oracle reproduces every bit.
+// fit_kernel: SPEC §6 on 8 workgroups x 1024 chains per option behind a counter barrier.
+// Every sum has the pinned order of SPEC §3.1 / §5 / §6 (no atomics on data): the CPU oracle reproduces every bit.
 // No upstream code exists to cite (reference = README.md:1-2); sections cite SPEC.md.
 #include "scg_device.hpp"
 #include "../../include/scg_abi.h"
