@@ -1,0 +1,65 @@
+"""Randomised parity sweep: batch sizes around the block and wave boundaries (1, 31, 33, 127, 129, 300, 1025),
+0..5 options with random enabled / gestation masks and option graphs, all three maps, learning and acting-only steps
+interleaved — every output of every step compared bit for bit with the oracle. Exercises the paths the fixed cases
+only touch lightly: ragged last blocks under the helper waves, evaluation-only value functions on the vector pipe
+with many entering envs, gestating options' off-policy items, stand-alone sorts after acting-only steps."""
+import numpy as np
+import pytest
+import torch
+
+import sc_oracle
+from gpu_util import assert_state_equal, dev, make_pair, state_to_device
+from util import disc_weights, random_states, random_weights
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, n_options, map, seed
+    (1, 0, "pinball_simple", 1), (1, 2, "pinball_empty", 2), (31, 1, "pinball_maze", 3), (33, 3, "pinball_simple", 4),
+    (127, 5, "pinball_simple", 5), (129, 5, "pinball_maze", 6), (300, 4, "pinball_empty", 7), (1025, 5, "pinball_simple", 8),
+    (640, 2, "pinball_maze", 9), (2000, 5, "pinball_simple", 10),
+]
+
+
+@pytest.mark.parametrize("n,nopt,mapname,seed", CASES)
+def test_random_configuration_rollout_bit_exact(n, nopt, mapname, seed):
+    rng = np.random.default_rng(seed)
+    known = int(rng.integers(0, 1 << nopt)) << 1 if nopt else 0
+    if nopt and known == 0:
+        known = 2
+    gest = known & (int(rng.integers(0, 1 << nopt)) << 1) if nopt else 0
+    enabled = known & ~gest
+    ctx, orc, m = make_pair(mapname, n, n_options=nopt, seed=seed, enabled_mask=enabled, max_episode_steps=25,
+                            max_option_steps=int(rng.integers(3, 12)), epsilon=float(rng.choice([0.0, 0.1, 0.5])))
+    parents = [0] + [int(rng.integers(0, k)) for k in range(1, nopt + 1)]          # acyclic: parent index < k
+    if nopt:
+        ctx.set_option_parents(parents); orc.set_parents(parents)
+    orc.set_gestation(gest); orc.set_trace(8)
+    ctx.set_trace_buffers(8)
+    succ_d = ctx.set_gestation(gest)
+    clf = np.zeros((nopt + 1, 8), np.float32)
+    tx, ty, _ = m.target
+    for k in range(1, nopt + 1):                                                    # overlapping discs all over the map
+        clf[k] = disc_weights(float(rng.uniform(0.2, 0.8)) if k > 1 else tx, float(rng.uniform(0.2, 0.8)) if k > 1 else ty,
+                              float(rng.uniform(0.15, 0.45)))
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 100 + seed, vmax=1.5)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    W_o = random_weights(nopt + 1, 200 + seed, std=0.05)
+    st_d, W_d, clf_d = state_to_device(st_o, ctx), dev(W_o.copy()), dev(clf)
+    G_d, nk_d = ctx.grad_buffers()
+    for t in range(14):
+        learn = (t % 5) != 3                                                        # an acting-only step now and then
+        if learn:
+            G, n_k = orc.step(st_o, W_o, clf, t)
+            orc.apply(W_o, G, n_k)
+        else:
+            G, n_k = orc.step(st_o, W_o, clf, t)                                    # oracle: same step, update discarded
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), enabled, t, learn=learn)
+        if learn:
+            assert np.array_equal(nk_d.cpu().numpy(), n_k), (t, nk_d.cpu().numpy(), n_k)
+            assert np.array_equal(G_d.cpu().numpy(), G), t
+        assert_state_equal(st_d, st_o, msg=f"step {t}")
+    torch.cuda.synchronize()
+    assert np.array_equal(W_d.cpu().numpy(), W_o)
+    assert np.array_equal(succ_d.cpu().numpy(), orc.gest_succ)
