@@ -60,7 +60,7 @@ typedef struct {
 #define SCG_STEP_APPLY 2u        /* apply it to W in the same call (single-rank path) */
 
 int scg_abi_version(void);
-int scg_block_envs(void);            /* SPEC §5 geometry this library was built with: 128 (4 waves, default) or 256 (8 waves) */
+int scg_block_envs(void);            /* SPEC §5 block size this library was built with: 128 envs (one 8-wavefront workgroup) */
 const char *scg_strerror(int status);
 const char *scg_last_error(const scg_ctx *ctx);
 

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--map", default="pinball_simple"); ap.add_argument("--envs", type=int, default=8192)
 ap.add_argument("--options", type=int, default=3); ap.add_argument("--alpha", type=float, default=0.02)
 ap.add_argument("--warm", type=int, default=3000); ap.add_argument("--after", type=int, default=3000)
+ap.add_argument("--gestation", type=int, default=0, help="successes a new option must see before it is enabled (SPEC 4.4)")
 a = ap.parse_args()
 ag = SkillChainingAgent(a.map, a.envs, a.options, seed=1, alpha=a.alpha, epsilon=0.05, gamma=0.99,
                         max_episode_steps=2000, max_option_steps=200, r_option_success=50.0)
@@ -30,7 +31,7 @@ def run(steps, tag):
 
 run(a.warm // 2, "root policy, first half ")
 run(a.warm // 2, "root policy, second half")
-report = ag.chain_skills(steps_per_option=400, min_examples=3000, max_examples=40000, start_coverage=0.9)
+report = ag.chain_skills(steps_per_option=400, min_examples=3000, max_examples=40000, start_coverage=0.9, gestation=a.gestation)
 for r in report:
     print("created", r, flush=True)
 inside = [(int((ag.state.option_id == k).sum())) for k in range(a.options + 1)]
