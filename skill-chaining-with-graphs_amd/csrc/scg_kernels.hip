@@ -358,6 +358,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
 
     // ------------------------------------------------------------------ phase P
+    if (helpers && wave < BLOCK_ENVS / 32) __builtin_amdgcn_s_setprio(2);   // phase P is the critical path: its waves issue
+                                                                             // ahead of the helper waves (which have slack)
     if (wave < BLOCK_ENVS / 32 && lane < 32) {        // 4 waves x 32 lanes (64-lane waves measured slower: 22.1k vs 18.8k
         const int i = wave * 32 + lane;               // cycles for the physics — more divergence per wave)
         const int e = (MODE == MODE_FUSED && A.perm && i < nb) ? A.perm[e0 + i] : e0 + i;
@@ -438,8 +440,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
                 s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
                 s_gs[i] = (uint8_t)inS; s_ia[i] = (uint8_t)((inA & 0x3Eu) | (goal ? 1u : 0u));
-                atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), (1u << (o & 31)) | (1u << (on & 31)) | inS);
-                atomicOr(reinterpret_cast<unsigned *>(&s_misc[30]), (1u << (o & 31)) | inS);
+                {   // bit masks of the VFs with items / update items here: OR over the wave's lanes first (7 ballots), then
+                    // one LDS atomic per wave instead of one per env on a single word
+                    const unsigned pm = (1u << (o & 31)) | (1u << (on & 31)) | inS, um = (1u << (o & 31)) | inS;
+                    unsigned pw = 0, uw = 0;
+#pragma unroll
+                    for (int k = 0; k < MAX_VF + 1; ++k) {
+                        if (__ballot((pm >> k) & 1u)) pw |= 1u << k;
+                        if (__ballot((um >> k) & 1u)) uw |= 1u << k;
+                    }
+                    if (lane == __builtin_ctzll(__ballot(true))) {
+                        atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), pw);
+                        atomicOr(reinterpret_cast<unsigned *>(&s_misc[30]), uw);
+                    }
+                }
                 if (inS && A.gest_succ) {                             // SPEC §4.4: gestation successes (integer counts: order-free)
 #pragma unroll
                     for (int k = 1; k < MAX_VF; ++k) {
@@ -517,7 +531,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         lds_arrive(&s_misc[28], 1);
         lds_await(&s_misc[28], WAVES - BLOCK_ENVS / 32);                               // W_0, Z(s) and the list are complete
         run_u1(hw, WAVES - BLOCK_ENVS / 32, rl, ro);
+#ifdef SCG_STAMPS
+        if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
+#endif
     }
+    if (helpers) __builtin_amdgcn_s_setprio(0);
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P

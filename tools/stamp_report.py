@@ -29,9 +29,9 @@ names = ["phase P (rest: trace, hist, barrier)", "root: phase Z + lists + W stag
          "root: barrier at pass start", "root: U2 (accumulate)", "root: wait before U2", "opt: lists + W staging", "opt: A operands -> registers",
          "opt: E (eval)", "opt: U1 (Q(s,a))", "opt: barrier at pass start", "opt: U2 (accumulate)", "opt: wait before U2", "slab stores",
          "P: perm, qcache, Philox, action", "P: state gathers", "P: physics", "P: bookkeeping, options, result line",
-         "U2: MFMAs of a chunk + wait, but the last", "U2: build", "U2: wait for the other waves' build", "lists: flags + ballots", "lists: W staging", "lists: barrier behind the staging", "eval-only: wait", "eval-only: VALU evaluation"] + ["-"] * 4
+         "U2: MFMAs of a chunk + wait, but the last", "U2: build", "U2: wait for the other waves' build", "lists: flags + ballots", "lists: W staging", "lists: barrier behind the staging", "eval-only: wait", "eval-only: VALU evaluation", "(helper wave 4: kernel start -> its U1 done; not part of the total)"] + ["-"] * 3
 mean = out.astype(np.float64).mean(0) / args.steps
-tot = mean.sum()
+tot = mean.sum() - mean[28]
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
 for nme, v in zip(names, mean): print(f"  {nme:36s} {v:10.0f}  {100*v/tot:5.1f} %")
 per_block = out.astype(np.float64).sum(1) / args.steps
