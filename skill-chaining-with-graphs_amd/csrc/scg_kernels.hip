@@ -794,15 +794,15 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
                         for (int s = 0; s < 2; ++s) { a2[s] = *reinterpret_cast<const float2 *>(pa[s] + 8 * gi); b2[s] = *reinterpret_cast<const float2 *>(pb[s] + 8 * gi); }
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].x, b2[s].x, accU[AA][s], 0, 0, 0);
+                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2[s].x, a2[s].x, accU[AA][s], 0, 0, 0);
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s].y, b2[s].y, accU[AA][s], 0, 0, 0);
+                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2[s].y, a2[s].y, accU[AA][s], 0, 0, 0);
                     }
                 } else {
                     for (int gi = 0; gi < ngrp; ++gi) {
                         const float2 a2 = *reinterpret_cast<const float2 *>(pa[0] + 8 * gi), b2 = *reinterpret_cast<const float2 *>(pb[0] + 8 * gi);
-                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, b2.x, accU[AA][0], 0, 0, 0);
-                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, b2.y, accU[AA][0], 0, 0, 0);
+                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.x, a2.x, accU[AA][0], 0, 0, 0);
+                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.y, a2.y, accU[AA][0], 0, 0, 0);
                     }
                 }
             };
@@ -811,10 +811,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             run_u2(std::integral_constant<int, 4>{});
         }
         SCG_STAMP(k == 0 ? 6 : 13);   // U2
-        // the block partial P_b,k straight from the accumulators (zeros for an empty run):
-        // tile (mi, ni), register v of lane (n16, g) = G[a][16 mi + 4 g + v][16 ni + n16]
+        // the block partial P_b,k straight from the accumulators (zeros for an empty run). The tiles were accumulated
+        // TRANSPOSED (A operand = CDT rows, B operand = PT rows; fma(a, b, c) = fma(b, a, c)), so register v of lane (n16, g)
+        // of tile (mi, ni) is G[a][c12 = 16 mi + n16][c34 = 16 ni + 4 g + v]: four consecutive floats per lane, one 16-byte
+        // store instead of four 4-byte ones (the epilogue is store-issue-bound)
         {
-            float *slab_lane = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF + (4 * g) * 36 + n16;
+            float *slab_lane = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF + n16 * 36 + 4 * g;
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
 #pragma unroll
@@ -822,12 +824,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     const int q = s == 0 ? ((wave_u - a) & 7) : 8;
                     if (s == 0 || wave_u == a) {
                         const int mi = (q * 11) >> 5, ni = q - 3 * mi;         // wave-uniform
-                        const bool okl = (mi < 2 || g == 0) && (ni < 2 || n16 < 4);
-                        float *dst = slab_lane + a * NF + (16 * mi) * 36 + 16 * ni;
-                        if (okl) {
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) gstore(dst + v * 36, accU[a][s][v]);
-                        }
+                        const bool okl = (mi < 2 || n16 < 4) && (ni < 2 || g == 0);
+                        if (okl) *reinterpret_cast<f4v *>(slab_lane + a * NF + (16 * mi) * 36 + 16 * ni) = accU[a][s];
                     }
                 }
             }
