@@ -540,16 +540,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 
     SCG_STAMP(0);   // phase P
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s and s_next
-    {
-        const int i = tid & (BLOCK_ENVS - 1), sg = tid / BLOCK_ENVS;
-        if (sg < 2 && i < nb && (MODE != MODE_QVAL || sg == 1) && !(helpers && sg == 0)) {
-            const float *st = s_s + sg * 4 * BLOCK_ENVS;
-            const float sv0 = st[i], sv1 = st[BLOCK_ENVS + i];
-            const float sv2 = fmaf(st[2 * BLOCK_ENVS + i], 0.25f, 0.5f), sv3 = fmaf(st[3 * BLOCK_ENVS + i], 0.25f, 0.5f);
-            const float2 za = sincospi_cs(sv0), zb = sincospi_cs(sv1), zc = sincospi_cs(sv2), zd = sincospi_cs(sv3);
-            float4 *dst = reinterpret_cast<float4 *>(s_z1 + (i * 2 + sg) * 4);
-            dst[0] = make_float4(za.x, za.y, zb.x, zb.y);
-            dst[1] = make_float4(zc.x, zc.y, zd.x, zd.y);
+    // one sincospi per thread and round: thread -> (env i, state sg, variable d)
+    for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {
+        const int i = u & (BLOCK_ENVS - 1), d = (u / BLOCK_ENVS) & 3, sg = u / (4 * BLOCK_ENVS);
+        if (i < nb && (MODE != MODE_QVAL || sg == 1) && !(helpers && sg == 0)) {
+            const float sv = s_s[(4 * sg + d) * BLOCK_ENVS + i];
+            s_z1[(i * 2 + sg) * 4 + d] = sincospi_cs(d < 2 ? sv : fmaf(sv, 0.25f, 0.5f));
         }
     }
 
