@@ -1442,8 +1442,8 @@ constexpr int FIT_G = 8, FIT_T = 1024, FIT_EPT = 8, FIT_BATCH = 8;
 constexpr int FIT_STRIDE = FIT_G * FIT_T;
 
 __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8_t *label, const int32_t *offsets,
-                                                    float *w, int iters, float lr, float l2, int q0, float *part,
-                                                    unsigned *cnt) {
+                                                    float *w, int iters, float lr, float l2, int q0,
+                                                    unsigned long long *part) {
     __shared__ float sw[8];
     __shared__ float swave[FIT_T / 64][6];
     __shared__ int s_abort;
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8
         }
     }
     const float invM = 1.0f / (float)M;
-    float *my_part = part + (size_t)ql * 2 * FIT_G * 8;
+    unsigned long long *my_part = part + (size_t)ql * 2 * FIT_G * 8;
     for (int it = 0; it < iters; ++it) {
         __syncthreads();
         float wl[6];
@@ -1493,31 +1493,40 @@ __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8
             if (lane == 0) swave[wave][jj] = g[jj];
         }
         __syncthreads();
-        float *buf = my_part + (it & 1) * FIT_G * 8;
+        // exchange of the workgroup partials: every value travels as ONE 64-bit word {iteration tag, float bits}, stored
+        // and polled with 64-bit relaxed agent-scope atomics — a value that carries the awaited tag is valid by itself, so
+        // the exchange costs one store and one (polled) load round trip; buffers alternate by iteration parity (a fast
+        // workgroup writes iteration it + 1 while a slow one still reads iteration it)
+        unsigned long long *buf = my_part + (it & 1) * FIT_G * 8;
+        const unsigned long long tag = (unsigned long long)(unsigned)(it + 1) << 32;
         if (tid < 6) {
             float ps = swave[0][tid];
 #pragma unroll
             for (int wv = 1; wv < FIT_T / 64; ++wv) ps = ps + swave[wv][tid];
-            __hip_atomic_store(&buf[j * 8 + tid], ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&buf[j * 8 + tid], tag | __float_as_uint(ps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tid == 0) {                                   // counter barrier over the option's FIT_G workgroups
-            __hip_atomic_fetch_add(&cnt[ql], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = (unsigned)FIT_G * (unsigned)(it + 1);
-            int spins = 0;
-            while (__hip_atomic_load(&cnt[ql], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 22)) { s_abort = 1; break; }      // never reached with co-resident workgroups
+        if (wave == 0) {
+            unsigned long long v = tag;
+            if (lane < 6 * FIT_G) {                          // lane -> (workgroup lane / 6, component lane % 6)
+                const unsigned long long *src = &buf[(lane / 6) * 8 + lane % 6];
+                int spins = 0;
+                while (((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (tag >> 32)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) { s_abort = 1; break; }      // never reached with co-resident workgroups
+                }
+            }
+            const float val = __uint_as_float((unsigned)v);
+            const int c = lane < 6 ? lane : 0;
+            float gs = __shfl(val, c, 64);                   // the FIT_G group sums in order
+#pragma unroll
+            for (int jw = 1; jw < FIT_G; ++jw) gs = gs + __shfl(val, jw * 6 + c, 64);
+            if (lane < 6) {
+                const float reg = (lane > 0) ? l2 * sw[lane] : 0.0f;
+                sw[lane] = sw[lane] - lr * ((gs * invM) + reg);
             }
         }
         __syncthreads();
         if (s_abort) break;
-        if (tid < 6) {
-            float gs = __hip_atomic_load(&buf[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int jw = 1; jw < FIT_G; ++jw) gs = gs + __hip_atomic_load(&buf[jw * 8 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float reg = (tid > 0) ? l2 * sw[tid] : 0.0f;
-            sw[tid] = sw[tid] - lr * ((gs * invM) + reg);
-        }
     }
     __syncthreads();
     if (j == 0 && tid < 6) w[CLF_STRIDE * q + tid] = s_abort ? __uint_as_float(0x7fc00000u) : sw[tid];
@@ -1534,8 +1543,7 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
-    float *d_fit_part;             // fit_kernel: workgroup partials [FIT_BATCH][2][FIT_G][8]
-    unsigned *d_fit_cnt;           // ... and the arrival counters of its barrier [FIT_BATCH]
+    unsigned long long *d_fit_part;   // fit_kernel: tagged workgroup partials [FIT_BATCH][2][FIT_G][8]
     float4 *d_outrec;              // [nblk * BLOCK_ENVS][4] per-position step results (td_kernel -> commit_row)
     int32_t *d_invperm;            // [n_envs] position of each env in d_perm
     int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
@@ -1655,8 +1663,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipMalloc(&c->d_fit_part, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipMalloc(&c->d_fit_cnt, FIT_BATCH * sizeof(unsigned)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_fit_part, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(unsigned long long)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_outrec, (size_t)c->nblk * BLOCK_ENVS * 4 * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_invperm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         {
@@ -1696,7 +1703,7 @@ int scg_destroy(scg_ctx *c) {
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
     (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]); (void)hipFree(c->d_outrec); (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
-    (void)hipFree(c->d_fit_part); (void)hipFree(c->d_fit_cnt);
+    (void)hipFree(c->d_fit_part);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -2110,9 +2117,9 @@ int scg_fit_initiation(scg_ctx *c, int32_t n_fit, const float *xy, const uint8_t
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     for (int q0 = 0; q0 < n_fit; q0 += FIT_BATCH) {        // FIT_G workgroups per option, at most 64 in flight: co-resident
         const int nb = n_fit - q0 < FIT_BATCH ? n_fit - q0 : FIT_BATCH;
-        SCG_HIP(c, hipMemsetAsync(c->d_fit_cnt, 0, FIT_BATCH * sizeof(unsigned), s));
+        SCG_HIP(c, hipMemsetAsync(c->d_fit_part, 0, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(unsigned long long), s));   // tags of a past call
         hipLaunchKernelGGL(fit_kernel, dim3(FIT_G, nb), dim3(FIT_T), 0, s, xy, label, offsets, w, iters, lr, l2, q0,
-                           c->d_fit_part, c->d_fit_cnt);
+                           c->d_fit_part);
         SCG_HIP(c, hipGetLastError());
     }
     return SCG_OK;
