@@ -275,8 +275,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 
     // U1: Q_k(s, a_t) of the update items, per action run, 8 items per wave-iteration: the contraction of E on the 3 row
     // tiles that hold action a's rows -> s_qsa[list position]. The column blocks of all runs are dealt to `nw` waves.
-    auto run_u1 = [&](int wv, int nw, const int (&rl)[NACT], const int (&ro)[NACT]) {
-        int base = 0;
+    auto run_u1 = [&](int wv, int nw, const int (&rl)[NACT], const int (&ro)[NACT], int base) {
 #pragma unroll 1
         for (int a = 0; a < NACT; ++a) {
             const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         lds_arrive(&s_misc[28], 1);
         lds_await(&s_misc[28], WAVES - BLOCK_ENVS / 32);                               // W_0, Z(s) and the list are complete
-        run_u1(hw, WAVES - BLOCK_ENVS / 32, rl, ro);
+        run_u1(hw, WAVES - BLOCK_ENVS / 32, rl, ro, 0);
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
@@ -707,7 +706,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
         // ---- U1 (the root's ran under phase P on the helper waves)
-        if (MODE != MODE_QVAL && nupd > 0 && !(helpers && k == 0)) run_u1(wave, WAVES, run_len, run_off);
+        if (MODE != MODE_QVAL && nupd > 0 && !(helpers && k == 0)) run_u1(wave, WAVES, run_len, run_off, nqe);   // dealt on behind E's blocks
         if (MODE == MODE_QVAL || nupd == 0) continue;
         SCG_STAMP(k == 0 ? 4 : 11);   // U1 (wave 0's share)
         block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
