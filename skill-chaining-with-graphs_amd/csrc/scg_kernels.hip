@@ -955,8 +955,18 @@ struct ReduceArgs {
 };
 
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
-constexpr int RED_WAVES = 16;      // one wave per segment, 16 segments per round
+#ifndef SCG_EXP_RW
+#define SCG_EXP_RW 16
+#endif
+#ifndef SCG_EXP_SB
+#define SCG_EXP_SB 1
+#endif
+constexpr int RED_WAVES = SCG_EXP_RW;
 constexpr int RED_THREADS = 64 * RED_WAVES;
+#ifndef SCG_EXP_SPW
+#define SCG_EXP_SPW 1
+#endif
+constexpr int RED_SPW = SCG_EXP_SPW;      // segments a wave sums per round
 constexpr int RED_COLS = NACT * NF / 4;                              // float4 columns per value function
 constexpr int RED_NCOL = (RED_COLS + 63) / 64;
 
@@ -1053,26 +1063,28 @@ __device__ __forceinline__ int order_pos0(const OrderLayout &L, int r) {       /
     return pos;
 }
 
-// One wave per row of 256 envs (no LDS, no barriers), two dependent memory round trips in all:
+// Four waves per row of 256 envs (wave wv owns envs 64 wv .. 64 wv + 63 of the row), two dependent memory round trips
+// and one workgroup barrier in all:
 //   commit: gather each env's result line from its position in the current order (one 64-byte read) and write
 //           the caller's SoA arrays (state, outputs, qcache) with full-line stores;
 //   sort  : place the row in the stable counting-sort order of the next step (7 keys), from the per-row key
-//           counts of all rows: offset(key k, row) = (envs with a smaller key) + (key-k envs of earlier rows).
-// Load order matters: positions first, then the count table, then the records, so that the table's latency hides
-// under the records' and the prefix sums run while the records are in flight.
-__device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int row) {
-    const int lane = threadIdx.x & 63;
-    int pos_old[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = row * 256 + j * 64 + lane;
-        pos_old[j] = e < R.n ? R.invperm[e] : 0;
-    }
+//           counts of all rows: offset(key k, row) = (envs with a smaller key) + (key-k envs of earlier rows)
+//           (+ key-k envs of the row's earlier waves, exchanged through LDS together with the waves' shares of the
+//           count table).
+// Every thread of the workgroup must call this (it holds the barrier); waves >= 4 only pass through it.
+// Load order matters: position first, then the count table, then the record, so that the table's latency hides
+// under the record's and the prefix sums run while the record is in flight. One wave per row (four envs per lane)
+// took 8.3 us of dependent work after the launch floor; see DESIGN §10.
+__device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int row, int wv, int lane, int (*s_x)[24]) {
+    const bool act = wv < 4 && row < R.nrow;
+    const int e = row * 256 + wv * 64 + lane;
+    const bool ok = act && e < R.n;
+    const int pos_old = ok ? R.invperm[e] : 0;
     int tot[7], pre[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) { tot[k] = 0; pre[k] = 0; }
-    if (R.sort) {
-        for (int r = lane; r < R.nrow; r += 64) {
+    if (act && R.sort) {
+        for (int r = wv * 64 + lane; r < R.nrow; r += 256) {       // this wave's quarter of the count table
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 const int h = R.hist[r * 8 + k];
@@ -1081,56 +1093,71 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
             }
         }
     }
-    float4 ra[4], rb[4], rq[4];
-    float q4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 *r = R.outrec + (size_t)pos_old[j] * 4;
-        ra[j] = r[0]; rb[j] = r[1]; rq[j] = r[2]; q4[j] = r[3].x;
+    float4 ra = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rb = ra, rq = ra;
+    float q4 = 0.0f;
+    if (ok) {
+        const float4 *r = R.outrec + (size_t)pos_old * 4;
+        ra = r[0]; rb = r[1]; rq = r[2]; q4 = r[3].x;
     }
-    int off[7];
-    OrderLayout L;
-    if (R.sort) {
+    int key = -1;
+    uint64_t km[7];
+    if (act) {
+        if (R.sort) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {                   // integer sums: any order
+            for (int k = 0; k < 7; ++k) {                   // integer sums: any order
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
+                for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
+            }
         }
-        order_layout(tot, R.n, L);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) off[k] = pre[k];    // rank of the row's first key-k env within its run
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = row * 256 + j * 64 + lane;
-        int key = -1;
-        if (e < R.n) {
-            const unsigned bits = __float_as_uint(rb[j].y);
+        const unsigned bits = __float_as_uint(rb.y);
+        if (ok) {
             key = (int)((bits >> 16) & 255u);
-            R.x[e] = ra[j].x; R.y[e] = ra[j].y; R.vx[e] = ra[j].z; R.vy[e] = ra[j].w;
-            R.reward[e] = rb[j].x; R.action[e] = (uint8_t)(bits & 255u); R.done[e] = (uint8_t)((bits >> 8) & 255u);
-            R.option_id_out[e] = key; R.opt_steps[e] = __float_as_int(rb[j].z); R.ep_steps[e] = __float_as_int(rb[j].w);
+            R.x[e] = ra.x; R.y[e] = ra.y; R.vx[e] = ra.z; R.vy[e] = ra.w;
+            R.reward[e] = rb.x; R.action[e] = (uint8_t)(bits & 255u); R.done[e] = (uint8_t)((bits >> 8) & 255u);
+            R.option_id_out[e] = key; R.opt_steps[e] = __float_as_int(rb.z); R.ep_steps[e] = __float_as_int(rb.w);
             if (R.qcache) {
                 const size_t n = (size_t)R.n;
-                R.qcache[e] = rq[j].x; R.qcache[n + e] = rq[j].y; R.qcache[2 * n + e] = rq[j].z;
-                R.qcache[3 * n + e] = rq[j].w; R.qcache[4 * n + e] = q4[j];
+                R.qcache[e] = rq.x; R.qcache[n + e] = rq.y; R.qcache[2 * n + e] = rq.z;
+                R.qcache[3 * n + e] = rq.w; R.qcache[4 * n + e] = q4;
             }
         }
         if (R.sort) {
-            int rk = -1, st = 0;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const uint64_t m = __ballot(key == k);
-                if (key == k) { rk = off[k] + __popcll(m & ((1ull << lane) - 1ull)); st = L.start[k]; }
-                off[k] += __popcll(m);
-            }
-            if (rk >= 0) {
-                const int pos = key == 0 ? order_pos0(L, rk) : order_posk(L, st, rk);
-                R.perm[pos] = e; R.invperm[e] = pos;
+            for (int k = 0; k < 7; ++k) km[k] = __ballot(key == k);
+            if (lane < 21) {                                // [0..6] table totals, [7..13] rows before this one, [14..20] this wave's keys
+                int v = 0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    if (lane == k) v = tot[k];
+                    if (lane == 7 + k) v = pre[k];
+                    if (lane == 14 + k) v = __popcll(km[k]);
+                }
+                s_x[wv][lane] = v;
             }
         }
     }
-    if (R.sort && lane < 8) R.hist_zero[row * 8 + lane] = 0;
+    if (!R.sort) return;                                    // workgroup-uniform
+    __syncthreads();
+    if (!act) return;
+    int off[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        tot[k] = s_x[0][k] + s_x[1][k] + s_x[2][k] + s_x[3][k];
+        off[k] = s_x[0][7 + k] + s_x[1][7 + k] + s_x[2][7 + k] + s_x[3][7 + k];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) off[k] += w < wv ? s_x[w][14 + k] : 0;      // rank of this wave's first key-k env within its run
+    }
+    OrderLayout L;
+    order_layout(tot, R.n, L);
+    int rk = -1, st = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (key == k) { rk = off[k] + __popcll(km[k] & ((1ull << lane) - 1ull)); st = L.start[k]; }
+    if (rk >= 0) {
+        const int pos = key == 0 ? order_pos0(L, rk) : order_posk(L, st, rk);
+        R.perm[pos] = e; R.invperm[e] = pos;
+    }
+    if (wv == 0 && lane < 8) R.hist_zero[row * 8 + lane] = 0;
 }
 
 // grid (column chunks, n_vf [+ rows of the env order]). A workgroup owns 64 float4 columns of one value function;
@@ -1138,15 +1165,15 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 // 16 loads in flight, park T_s in LDS, and wave 0 adds the non-empty segments in order, G = ((T_0 + T_1) + ...)
 // — SPEC §5's two levels in one launch.
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
-    __shared__ float4 s_T[RED_WAVES][64];
-    __shared__ int s_cnt[RED_WAVES];
+    __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
+    __shared__ int s_cnt[RED_WAVES * RED_SPW < 96 ? 96 : RED_WAVES * RED_SPW];   // (the commit rows use it as their [4][24] exchange area)
     // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
     const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
     const int rowy = (int)blockIdx.y - R.n_vf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k < 0) {
-        const int row = rowy * (int)gridDim.x + blockIdx.x;                 // one row per workgroup (wave 0): a row
-        if (wave == 0 && row < R.nrow) commit_and_place_row(R, row);        // moves ~25 KB, so spread them over the CUs
+        const int row = rowy * (int)gridDim.x + blockIdx.x;                 // one row per workgroup (waves 0..3): a row
+        commit_and_place_row(R, row, wave, lane, reinterpret_cast<int (*)[24]>(&s_cnt[0]));   // moves ~25 KB, so spread them over the CUs
         return;
     }
     const int i4 = blockIdx.x * 64 + lane;
@@ -1163,32 +1190,47 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         w_old = *wp;
         sc = *reinterpret_cast<const float4 *>(R.scale + ((live ? i4 : 0) * 4) % NF);     // NF % 4 == 0: no row straddling
     }
-    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES) {
-        const int b0 = (sg0 + wave) * SEG;
-        const int bl = b0 + lane;
-        int c = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
-        const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
+    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES * RED_SPW) {
+        // a wave takes RED_SPW segments per round (sg0 + wave, sg0 + RED_WAVES + wave, ...): their counts are fetched
+        // together and the second segment's slab loads follow the first's sums without a workgroup barrier in between
+        int cj[RED_SPW];
 #pragma unroll
-        for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
-        float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (mask) {
-            float4 v[SEG];
-#pragma unroll
-            for (int u = 0; u < SEG; ++u) {
-                v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if ((mask >> u) & 1u) v[u] = p[(size_t)(b0 + u) * stride4];
-            }
-#pragma unroll
-            for (int u = 0; u < SEG; ++u) {
-                if ((mask >> u) & 1u) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
-            }
+        for (int j = 0; j < RED_SPW; ++j) {
+            const int bl = (sg0 + j * RED_WAVES + wave) * SEG + lane;
+            cj[j] = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
         }
-        s_T[wave][lane] = T;
-        if (lane == 0) s_cnt[wave] = c;
+#pragma unroll
+        for (int j = 0; j < RED_SPW; ++j) {
+            const int b0 = (sg0 + j * RED_WAVES + wave) * SEG;
+            int c = cj[j];
+#ifdef SCG_EXP_NOSLAB
+            const unsigned mask = 0;
+#else
+            const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
+#endif
+#pragma unroll
+            for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
+            float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (mask) {
+                float4 v[SEG];
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) {
+                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if ((mask >> u) & 1u) v[u] = p[(size_t)(b0 + u) * stride4];
+                }
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) {
+                    if ((mask >> u) & 1u) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
+                }
+            }
+            s_T[j * RED_WAVES + wave][lane] = T;
+            if (lane == 0) s_cnt[j * RED_WAVES + wave] = c;
+            if (j % SCG_EXP_SB == SCG_EXP_SB - 1) __builtin_amdgcn_sched_barrier(0);   // keep the next segments' loads behind these sums (registers)
+        }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int u = 0; u < RED_WAVES; ++u) {
+            for (int u = 0; u < RED_WAVES * RED_SPW; ++u) {
                 const int cu = s_cnt[u];
                 if (cu > 0) {
                     const float4 t = s_T[u][lane];
@@ -1197,7 +1239,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
                 }
             }
         }
-        __syncthreads();
+        if (sg0 + RED_WAVES * RED_SPW < nseg) __syncthreads();
     }
     if (wave != 0) return;
     if (blockIdx.x == 0 && lane == 0) {
@@ -1215,10 +1257,14 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     }
 }
 
-// acting-only steps have no reduce launch: the commit alone, one wave per row of 256 envs
+#ifdef SCG_EXP_PROBE
+__global__ void probe_kernel(const int32_t *p) { if (p == nullptr) __builtin_trap(); }
+#endif
+
+// acting-only steps have no reduce launch: the commit alone, one workgroup of four waves per row of 256 envs
 __global__ __launch_bounds__(256) void commit_kernel(const ReduceArgs R) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row < R.nrow) commit_and_place_row(R, row);
+    __shared__ int s_x[4][24];
+    commit_and_place_row(R, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, s_x);
 }
 
 __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, const int32_t *n_k, const float *nk_f,
@@ -1801,12 +1847,18 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
         R.qcache = st->k_hi >= 0 ? st->qcache : nullptr;
     }
     if (!reduce) {                                       // acting-only step: the commit alone
-        hipLaunchKernelGGL(commit_kernel, dim3((nrow + 3) / 4), dim3(256), 0, s, R);
+        hipLaunchKernelGGL(commit_kernel, dim3(nrow), dim3(256), 0, s, R);
         SCG_HIP(c, hipGetLastError());
         return SCG_OK;
     }
     const int sy = (nrow + RED_NCOL - 1) / RED_NCOL;
+#ifdef SCG_EXP_PROBE     // diagnostic builds: what does the launch behind td_kernel cost before it does anything?
+    hipLaunchKernelGGL(probe_kernel, dim3(SCG_EXP_PROBE), dim3(64), 0, s, c->d_hist);
+#endif
     hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
+#ifdef SCG_EXP_PROBE
+    { ReduceArgs R2 = R; R2.apply = 0; hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf), dim3(RED_THREADS), 0, s, R2); }
+#endif
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
