@@ -955,18 +955,8 @@ struct ReduceArgs {
 };
 
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
-#ifndef SCG_EXP_RW
-#define SCG_EXP_RW 16
-#endif
-#ifndef SCG_EXP_SB
-#define SCG_EXP_SB 1
-#endif
-constexpr int RED_WAVES = SCG_EXP_RW;
+constexpr int RED_WAVES = 16;      // one wave per segment, 16 segments per round
 constexpr int RED_THREADS = 64 * RED_WAVES;
-#ifndef SCG_EXP_SPW
-#define SCG_EXP_SPW 1
-#endif
-constexpr int RED_SPW = SCG_EXP_SPW;      // segments a wave sums per round
 constexpr int RED_COLS = NACT * NF / 4;                              // float4 columns per value function
 constexpr int RED_NCOL = (RED_COLS + 63) / 64;
 
@@ -1165,15 +1155,16 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 // 16 loads in flight, park T_s in LDS, and wave 0 adds the non-empty segments in order, G = ((T_0 + T_1) + ...)
 // — SPEC §5's two levels in one launch.
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
-    __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
-    __shared__ int s_cnt[RED_WAVES * RED_SPW < 96 ? 96 : RED_WAVES * RED_SPW];   // (the commit rows use it as their [4][24] exchange area)
+    __shared__ float4 s_T[RED_WAVES][64];
+    __shared__ int s_cnt[RED_WAVES];
+    __shared__ int s_x[4][24];         // the commit rows' exchange area
     // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
     const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
     const int rowy = (int)blockIdx.y - R.n_vf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k < 0) {
         const int row = rowy * (int)gridDim.x + blockIdx.x;                 // one row per workgroup (waves 0..3): a row
-        commit_and_place_row(R, row, wave, lane, reinterpret_cast<int (*)[24]>(&s_cnt[0]));   // moves ~25 KB, so spread them over the CUs
+        commit_and_place_row(R, row, wave, lane, s_x);                      // moves ~25 KB, so spread them over the CUs
         return;
     }
     const int i4 = blockIdx.x * 64 + lane;
@@ -1190,47 +1181,32 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         w_old = *wp;
         sc = *reinterpret_cast<const float4 *>(R.scale + ((live ? i4 : 0) * 4) % NF);     // NF % 4 == 0: no row straddling
     }
-    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES * RED_SPW) {
-        // a wave takes RED_SPW segments per round (sg0 + wave, sg0 + RED_WAVES + wave, ...): their counts are fetched
-        // together and the second segment's slab loads follow the first's sums without a workgroup barrier in between
-        int cj[RED_SPW];
+    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES) {
+        const int b0 = (sg0 + wave) * SEG;
+        const int bl = b0 + lane;
+        int c = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
+        const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
 #pragma unroll
-        for (int j = 0; j < RED_SPW; ++j) {
-            const int bl = (sg0 + j * RED_WAVES + wave) * SEG + lane;
-            cj[j] = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
-        }
+        for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
+        float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (mask) {
+            float4 v[SEG];
 #pragma unroll
-        for (int j = 0; j < RED_SPW; ++j) {
-            const int b0 = (sg0 + j * RED_WAVES + wave) * SEG;
-            int c = cj[j];
-#ifdef SCG_EXP_NOSLAB
-            const unsigned mask = 0;
-#else
-            const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
-#endif
-#pragma unroll
-            for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
-            float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (mask) {
-                float4 v[SEG];
-#pragma unroll
-                for (int u = 0; u < SEG; ++u) {
-                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if ((mask >> u) & 1u) v[u] = p[(size_t)(b0 + u) * stride4];
-                }
-#pragma unroll
-                for (int u = 0; u < SEG; ++u) {
-                    if ((mask >> u) & 1u) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
-                }
+            for (int u = 0; u < SEG; ++u) {
+                v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if ((mask >> u) & 1u) v[u] = p[(size_t)(b0 + u) * stride4];
             }
-            s_T[j * RED_WAVES + wave][lane] = T;
-            if (lane == 0) s_cnt[j * RED_WAVES + wave] = c;
-            if (j % SCG_EXP_SB == SCG_EXP_SB - 1) __builtin_amdgcn_sched_barrier(0);   // keep the next segments' loads behind these sums (registers)
+#pragma unroll
+            for (int u = 0; u < SEG; ++u) {
+                if ((mask >> u) & 1u) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
+            }
         }
+        s_T[wave][lane] = T;
+        if (lane == 0) s_cnt[wave] = c;
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int u = 0; u < RED_WAVES * RED_SPW; ++u) {
+            for (int u = 0; u < RED_WAVES; ++u) {
                 const int cu = s_cnt[u];
                 if (cu > 0) {
                     const float4 t = s_T[u][lane];
@@ -1239,7 +1215,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
                 }
             }
         }
-        if (sg0 + RED_WAVES * RED_SPW < nseg) __syncthreads();
+        __syncthreads();
     }
     if (wave != 0) return;
     if (blockIdx.x == 0 && lane == 0) {
@@ -1256,10 +1232,6 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         *wp = w;
     }
 }
-
-#ifdef SCG_EXP_PROBE
-__global__ void probe_kernel(const int32_t *p) { if (p == nullptr) __builtin_trap(); }
-#endif
 
 // acting-only steps have no reduce launch: the commit alone, one workgroup of four waves per row of 256 envs
 __global__ __launch_bounds__(256) void commit_kernel(const ReduceArgs R) {
@@ -1852,13 +1824,7 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
         return SCG_OK;
     }
     const int sy = (nrow + RED_NCOL - 1) / RED_NCOL;
-#ifdef SCG_EXP_PROBE     // diagnostic builds: what does the launch behind td_kernel cost before it does anything?
-    hipLaunchKernelGGL(probe_kernel, dim3(SCG_EXP_PROBE), dim3(64), 0, s, c->d_hist);
-#endif
     hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
-#ifdef SCG_EXP_PROBE
-    { ReduceArgs R2 = R; R2.apply = 0; hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf), dim3(RED_THREADS), 0, s, R2); }
-#endif
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
