@@ -63,3 +63,33 @@ def test_random_configuration_rollout_bit_exact(n, nopt, mapname, seed):
     torch.cuda.synchronize()
     assert np.array_equal(W_d.cpu().numpy(), W_o)
     assert np.array_equal(succ_d.cpu().numpy(), orc.gest_succ)
+
+
+def test_long_rollout_bit_exact():
+    """300 learning steps of one batch (1536 envs, 4 chained options, episodes of at most 40 steps, a large step size
+    so that the weights move by orders of magnitude): resets, time-outs, option entries and exits many times over;
+    the whole state is compared after every step, G / n_k / W every 25."""
+    n, nopt = 1536, 4
+    enabled = 0b11110
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=nopt, seed=77, enabled_mask=enabled, max_episode_steps=40,
+                            max_option_steps=9, epsilon=0.2, alpha=2e-2)
+    from util import chain_classifiers
+    clf = chain_classifiers(m, nopt)
+    st_o = sc_oracle.new_state(n, m)
+    x, y, vx, vy = random_states(m, n, 4242, vmax=1.0)
+    st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = x, y, vx, vy
+    W_o = random_weights(nopt + 1, 4243, std=0.02)
+    st_d, W_d, clf_d = state_to_device(st_o, ctx), dev(W_o.copy()), dev(clf)
+    G_d, nk_d = ctx.grad_buffers()
+    goals = timeouts = 0
+    for t in range(300):
+        G, n_k = orc.step(st_o, W_o, clf, t)
+        orc.apply(W_o, G, n_k)
+        ctx.step(st_d, W_d.view(-1), clf_d.view(-1), enabled, t, learn=True)
+        assert_state_equal(st_d, st_o, msg=f"step {t}")
+        goals += int((st_o["done"] == 1).sum()); timeouts += int((st_o["done"] == 2).sum())
+        if t % 25 == 24:
+            assert np.array_equal(nk_d.cpu().numpy(), n_k), t
+            assert np.array_equal(G_d.cpu().numpy(), G), t
+            assert np.array_equal(W_d.cpu().numpy(), W_o), t
+    assert np.isfinite(W_o).all() and goals > 0 and timeouts > 0
