@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--diag-fresh-sort", action="store_true", help="diagnostic: stand-alone sort kernels every step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--event-every", type=int, default=0, help="HIP event pair round every n-th fused-kernel launch "
-                    "(0 = max(2, steps // 8): each pair costs a few us of queue bubble, so at most every other launch is sampled)")
+                    "(0 = max(4, steps // 8): each pair costs a few us of queue bubble — 3 us per step when every other launch is sampled)")
     ap.add_argument("--ramp", type=int, default=200, help="untimed clock-ramp step-batches before the warm-up "
                     "(a 20-step run otherwise times a cold GPU and the first step's stand-alone sort)")
     args = ap.parse_args()
@@ -218,7 +218,7 @@ def main():
     for _ in range(args.warmup):
         agent.step_batch(learn)
     barrier()
-    event_every = args.event_every if args.event_every > 0 else max(2, args.steps // 8)
+    event_every = args.event_every if args.event_every > 0 else max(4, args.steps // 8)
     lib.scg_profile_reset(ctx, event_every)       # HIP events round the fused kernel, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,8 +255,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(n_local, n_opt), "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                         "note": "the fused kernel is bound by the f32 matrix pipe, not by HBM (SURVEY.md \u00a78d, DESIGN.md): "
-                                 "see `mfma` for the binding roofline"},
+                         "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 44 % busy), not HBM-bound (SURVEY.md \u00a78d, "
+                                 "DESIGN.md): see `mfma` for the binding roofline"},
         }
         # the binding (matrix-pipe) roofline: algorithmic flops of the TD items this rank processed per step
         st = agent.state
