@@ -80,6 +80,28 @@ def measured_traffic(envs_per_gpu, n_options):
     return None
 
 
+def host_cpu_share():
+    """CPUs this process can really use: the affinity mask capped by the cgroup CPU quota (a 1-GPU box of the pool shows
+    256 CPUs in its mask and a quota of 16; 256 OpenMP threads inside that quota run 6x SLOWER than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                                   # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:                                                                        # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(seconds_target=15.0):
     """Time the CPU oracle on a bounded sample of the same workload (same map, options, hyper-params): first
     one thread (a third of the budget), then all host cores (SURVEY §8d asks for both)."""
@@ -87,7 +109,7 @@ def cpu_baseline(seconds_target=15.0):
     import sc_oracle
     import skill_chaining_with_graphs_amd as scg
     from skill_chaining_with_graphs_amd.core import fourier_scale_table
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cpu_share()
     m = scg.load_map(MAP)
     clf = chain_discs(m, N_OPTIONS)
 
@@ -117,7 +139,7 @@ def cpu_baseline(seconds_target=15.0):
     vc, nc, sc, dc = timed(cores, seconds_target * 2.0 / 3.0)
     return {"value": vc, "unit": "env-steps/s", "cores": cores, "kind": "port", "single_thread_value": v1,
             "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, scalar fmaf chains, OpenMP over 128-env blocks; `cores` = "
-                      f"every core this process may run on), same workload: "
+                      f"the CPUs this process may use: affinity mask capped by the cgroup quota), same workload: "
                       f"{nc} envs x {sc} step-batches on {cores} threads in {dc:.1f} s; {n1} envs x {s1} step-batches "
                       f"on 1 thread in {d1:.1f} s; the upstream reference ships no code to time"}
 
