@@ -76,11 +76,14 @@ static void state_tables(float x, float y, float vx, float vy, cplx AB[36], cplx
         sco_sincospi(sh[d], &Z[d][1].re, &Z[d][1].im);
         for (int k = 2; k < 6; ++k) Z[d][k] = cmul(Z[d][k - 1], Z[d][1]);
     }
-    for (int a = 0; a < 6; ++a)
-        for (int b = 0; b < 6; ++b) {
-            AB[a * 6 + b] = cmul(Z[0][a], Z[1][b]);
-            CD[a * 6 + b] = cmul(Z[2][a], Z[3][b]);
+    for (int b = 0; b < 6; ++b) {                 /* row 0 is the power itself, row c the row above times Z^1 */
+        AB[b] = Z[1][b];
+        CD[b] = Z[3][b];
+        for (int a = 1; a < 6; ++a) {
+            AB[a * 6 + b] = cmul(AB[(a - 1) * 6 + b], Z[0][1]);
+            CD[a * 6 + b] = cmul(CD[(a - 1) * 6 + b], Z[2][1]);
         }
+    }
 }
 
 static void state_features(float x, float y, float vx, float vy, float *phi) {

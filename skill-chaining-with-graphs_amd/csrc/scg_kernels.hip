@@ -154,7 +154,8 @@ __device__ __forceinline__ bool in_set(const StepArgs &A, int k, float x, float 
 // ------------------------------------------------------------------------------------------------
 // SPEC §3 tables of one item from its four Z_d^1 (z1p: 4 float2 in LDS). The calling lane owns second index
 // `cp` (c2 of AB, c4 of CD; cp < 6) and gets, for the first index c = 0..5, AB[6c + cp] and CD[6c + cp]:
-// AB[c1*6 + c2] = cmul(Z_0^c1, Z_1^c2), CD[c3*6 + c4] = cmul(Z_2^c3, Z_3^c4), Z^0 = (1, 0), Z^k = cmul(Z^(k-1), Z^1).
+// AB[c2] = Z_1^c2, AB[c1*6 + c2] = cmul(AB[(c1-1)*6 + c2], Z_0^1) (CD likewise from Z_3, Z_2), Z^0 = (1, 0), Z^k = cmul(Z^(k-1), Z^1):
+// five chained products per table column instead of a power chain plus a product per entry.
 __device__ __forceinline__ float2 zpow_sel(float2 z, int c) {
     float2 cur = z, out = make_float2(1.0f, 0.0f);
 #pragma unroll
@@ -168,14 +169,11 @@ __device__ __forceinline__ void item_entries(const float2 *z1p, int cp, float2 (
     const float4 za = *reinterpret_cast<const float4 *>(z1p), zc = *reinterpret_cast<const float4 *>(z1p + 2);
     const float2 z0 = make_float2(za.x, za.y), z1 = make_float2(za.z, za.w);
     const float2 z2 = make_float2(zc.x, zc.y), z3 = make_float2(zc.z, zc.w);
-    const float2 pb = zpow_sel(z1, cp), pd = zpow_sel(z3, cp);
-    float2 pa = make_float2(1.0f, 0.0f), pc = make_float2(1.0f, 0.0f);
+    ab[0] = zpow_sel(z1, cp); cd[0] = zpow_sel(z3, cp);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        if (c == 1) { pa = z0; pc = z2; }
-        if (c > 1) { pa = cmul(pa, z0); pc = cmul(pc, z2); }
-        ab[c] = cmul(pa, pb);
-        cd[c] = cmul(pc, pd);
+    for (int c = 1; c < 6; ++c) {
+        ab[c] = cmul(ab[c - 1], z0);
+        cd[c] = cmul(cd[c - 1], z2);
     }
 }
 
@@ -856,8 +854,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                         const float4 *zp = reinterpret_cast<const float4 *>(s_z1 + (il * 2 + 1) * 4);
                         const float4 za = zp[0], zc = zp[1];
                         const int hi = (lane * 43) >> 8, lo = lane - 6 * hi;                  // lane / 6, lane % 6 for lane < 36
-                        const float2 ab = cmul(zpow_sel(make_float2(za.x, za.y), hi), zpow_sel(make_float2(za.z, za.w), lo));
-                        const float2 cd = cmul(zpow_sel(make_float2(zc.x, zc.y), hi), zpow_sel(make_float2(zc.z, zc.w), lo));
+                        float2 ab = zpow_sel(make_float2(za.z, za.w), lo), cd = zpow_sel(make_float2(zc.z, zc.w), lo);
+#pragma unroll
+                        for (int c = 1; c < 6; ++c) {                                         // row hi: hi chained products
+                            const float2 abn = cmul(ab, make_float2(za.x, za.y)), cdn = cmul(cd, make_float2(zc.x, zc.y));
+                            if (c <= hi) { ab = abn; cd = cdn; }
+                        }
                         t_ab[lane] = make_float2(ab.x, -ab.y);
                         t_cd[lane] = cd;
                     }
@@ -1435,7 +1437,9 @@ __global__ __launch_bounds__(64) void features_kernel(int n, const float *x, con
         wave_lds_sync();
         for (int p = lane; p < 72; p += 64) {
             const int q = p % 36, d0 = p < 36 ? 0 : 2;
-            s_abcd[p] = cmul(pow_at(s_pw, d0, q / 6), pow_at(s_pw, d0 + 1, q % 6));
+            float2 v = pow_at(s_pw, d0 + 1, q % 6);                       // row 0; row c = row c - 1 times Z_d0^1
+            for (int c = 1; c <= q / 6; ++c) v = cmul(v, pow_at(s_pw, d0, 1));
+            s_abcd[p] = v;
         }
         wave_lds_sync();
         for (int f = lane; f < NF; f += 64) {

@@ -67,8 +67,15 @@ def _q_numpy_f32(x, y, vx, vy, W):
     def cm(a, b):
         return (fma(-a[1], b[1], f32(a[0] * b[0])), fma(a[0], b[1], f32(a[1] * b[0])))
 
-    AB = [cm(Z[0][i], Z[1][j]) for i in range(6) for j in range(6)]
-    CD = [cm(Z[2][i], Z[3][j]) for i in range(6) for j in range(6)]
+    def table(zrow, zcol):                # SPEC §3: row 0 = powers of zcol, row i = row i - 1 times zrow^1
+        t = [[None] * 6 for _ in range(6)]
+        for j in range(6):
+            t[0][j] = zcol[j]
+            for i in range(1, 6):
+                t[i][j] = cm(t[i - 1][j], zrow[1])
+        return [t[i][j] for i in range(6) for j in range(6)]
+
+    AB, CD = table(Z[0], Z[1]), table(Z[2], Z[3])
     out = []
     for a in range(5):
         q = [[f32(0), f32(0)] for _ in range(4)]
