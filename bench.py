@@ -66,18 +66,23 @@ except (OSError, ValueError):
     pass
 
 
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")      # newest first
+
+
 def measured_traffic(envs_per_gpu, n_options):
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate passes; profiles/r02_traffic.json) — only when it was taken on this exact workload."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
-            t = json.load(f)
-        w = t["workload"]
-        if w["envs_per_gpu"] == envs_per_gpu and w["n_options"] == n_options and w["map"] == MAP:
-            return t["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    """(bytes, source): HBM bytes per launch of the dominant kernel from the newest committed PMC profile (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE, separate passes, the guide's corrections applied; profiles/rNN_traffic.json) — only
+    when it was taken on this exact workload. A STATIC figure read from a tracked file: this run does not measure it."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            w = t["workload"]
+            if w["envs_per_gpu"] == envs_per_gpu and w["n_options"] == n_options and w["map"] == MAP:
+                return t["traffic_bytes_per_launch"], f"profiles/{name} (static: rocprofv3 PMC passes of an earlier run of this workload, not measured by this run)"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def host_cpu_share():
@@ -242,6 +247,8 @@ def main():
     barrier()
     event_every = args.event_every if args.event_every > 0 else max(4, args.steps // 8)
     lib.scg_profile_reset(ctx, event_every)       # HIP events round the fused kernel, on the launch stream
+    if group is not None:
+        agent.time_allreduce(event_every)         # ... and round the shared-weights all-reduce, as the step's stream sees it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.step_batch(learn)
@@ -252,8 +259,15 @@ def main():
     lib.scg_profile_read(ctx, C.byref(k_ms), C.byref(k_n))
     lib.scg_profile_reset(ctx, 0)
 
+    ar = agent.time_allreduce(0) if group is not None else None
     t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    dt_ranks = [dt]
+    world_seen = 1
     if distributed:
+        world_seen = dist.get_world_size()        # what the process group really holds (not the --gpus flag)
+        every = [torch.zeros_like(t) for _ in range(world_seen)]
+        dist.all_gather(every, t)
+        dt_ranks = [float(v.item()) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
     total_env_steps = float(n_local) * world * args.steps
@@ -264,18 +278,27 @@ def main():
         kern_ms = k_ms.value / max(k_n.value, 1)
         units = n_local
         achieved = units * BYTES_PER_ENV_STEP / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic, traffic_source = measured_traffic(n_local, n_opt)
         out = {
             "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "untimed_ramp_steps": args.ramp, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_local} envs/GPU x {world} GPU, map {MAP}, Fourier order 5 (1296 terms), "
                                    f"root + {n_opt} chained options (synthetic nested-disc initiation sets), "
                                    f"{'shared option-Q weights, RCCL all-reduce of dW' if group is not None else 'independent env shards, no collective'}",
-                       "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP},
+                       "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP,
+                       "untimed_ramp_steps": args.ramp,      # step-batches run BEFORE the warm-up: clocks up, env order prepared;
+                                                              # `value` is therefore a steady-state figure
+                       "backend": ("none" if not distributed else args.backend)},
+            "ranks": {"world_size_seen": world_seen, "ms_per_step_min": min(dt_ranks) / args.steps * 1e3,
+                      "ms_per_step_max": max(dt_ranks) / args.steps * 1e3,
+                      "allreduce": (None if ar is None else dict(ar, bytes=int(agent.ctx.grad_packed().numel()) * 4,
+                                    note="event pair on the step's stream round the packed all-reduce of rank 0: the collective "
+                                         "as the step sees it (fully exposed: the next launch needs its result)"))},
             "roofline": {"bound": "hbm", "kernel": "td_kernel<MODE_FUSED>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(n_local, n_opt), "kernel_ms": kern_ms, "launches": int(k_n.value),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                          "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 44 % busy), not HBM-bound (SURVEY.md \u00a78d, "
                                  "DESIGN.md): see `mfma` for the binding roofline"},

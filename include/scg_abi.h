@@ -39,7 +39,8 @@ typedef enum {
     SCG_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
     SCG_ERR_NO_DEVICE = -2,    /* no HIP device / wrong architecture */
     SCG_ERR_HIP = -3,          /* a HIP runtime call failed */
-    SCG_ERR_STATE = -4         /* call order (e.g. step before set_map) */
+    SCG_ERR_STATE = -4,        /* call order (e.g. step before set_map) */
+    SCG_ERR_ASYNC = -5         /* a kernel launched earlier gave up on the device (sticky; see "asynchronous failures") */
 } scg_status;
 
 typedef struct scg_ctx scg_ctx;
@@ -167,6 +168,26 @@ int scg_collect_examples(scg_ctx *ctx, uint32_t event_bits, uint8_t *prev_in, in
  * caller-owned, may be NULL) counts the transitions that reached option k's target from inside its initiation set.
  * The caller moves the bit from gest_mask to scg_step's enabled_mask when the count is high enough. */
 int scg_set_gestation(scg_ctx *ctx, uint32_t gest_mask, int32_t *succ_counts);
+
+/* ---- asynchronous failures ----
+ * Launches are asynchronous, so a kernel that has to give up cannot return a status. It leaves its outputs untouched
+ * and ORs a reason into a host-visible status word owned by the ctx; from then on EVERY entry point that would launch
+ * work returns SCG_ERR_ASYNC (scg_last_error names the reason) until scg_clear_async_error is called. Today one
+ * kernel can do this: scg_fit_initiation's — the eight workgroups of a fit problem exchange partial sums through
+ * memory every iteration and need to be running at the same time; if the card is shared (another stream, another
+ * process) a workgroup may be kept off it. A missing partner is waited for scg_set_fit_timeout seconds of wall clock
+ * (default 2 s), then the fit of that problem is abandoned: its row of `w` keeps the values it had, never a partial
+ * result or a NaN. Word layout: SCG_ASYNC_FIT_TIMEOUT | 0x100 << (problem index & 15).
+ *   scg_async_status      the word (optional out) and its status; `synchronize` != 0 waits for `stream` first, which
+ *                         makes the answer final for everything launched on it so far
+ *   scg_decode_async_word the same mapping word -> status + text without a ctx (pure host code) */
+#define SCG_ASYNC_FIT_TIMEOUT 0x1u
+int scg_async_status(scg_ctx *ctx, void *stream, int32_t synchronize, uint32_t *word_out);
+int scg_clear_async_error(scg_ctx *ctx);
+int scg_set_fit_timeout(scg_ctx *ctx, double seconds);
+int scg_decode_async_word(uint32_t word, char *buf, int32_t buf_len);
+/* test hook: raise bits of the status word from the host, as a kernel would */
+int scg_debug_raise_async(scg_ctx *ctx, uint32_t word);
 
 /* ---- measurement hooks (bench.py's roofline leg) ----
  * scg_profile_reset(ctx, p) with p >= 1 makes every p-th following scg_step record a HIP event pair round

@@ -70,6 +70,11 @@ _SIGS = {
     "scg_profile_reset": (C.c_int, [_P, C.c_int32]),
     "scg_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "scg_fit_initiation": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_float, _P]),
+    "scg_async_status": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_uint32)]),
+    "scg_clear_async_error": (C.c_int, [_P]),
+    "scg_set_fit_timeout": (C.c_int, [_P, C.c_double]),
+    "scg_decode_async_word": (C.c_int, [C.c_uint32, C.c_char_p, C.c_int32]),
+    "scg_debug_raise_async": (C.c_int, [_P, C.c_uint32]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

@@ -33,6 +33,7 @@ class SkillChainingAgent:
         self._gest_need = {}
         self.t = 0
         self.group = group            # torch.distributed group for shared option-Q weights (or None)
+        self.allreduce_timing = None  # see time_allreduce()
         self.domain = PinballDomain(self.ctx)
         self.state: EnvState = self.domain.state
         self.options: List[Option] = [Option(self, k) for k in range(self.n_vf)]
@@ -202,9 +203,31 @@ class SkillChainingAgent:
             gp = self.ctx.grad_packed()                  # G and the update counts: ONE all-reduce operand
         self.ctx.step(self.state, self.W, self.clf, self.enabled_mask, self.t, learn=learn, apply=not shared)
         if shared:
+            timing = self.allreduce_timing
+            sample = timing is not None and (self.t % timing["every"]) == 0
+            if sample:                                   # measurement hook (bench.py): events on the stream of use
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             _dist.allreduce_packed(gp, self.group)      # RCCL over xGMI: one latency-bound 26 KB x n_vf message
+            if sample:
+                e1.record()
+                timing["events"].append((e0, e1))
             self.ctx.apply_update_packed(self.W, gp)
         self.t += 1
+
+    def time_allreduce(self, every: int = 0) -> Optional[dict]:
+        """every > 0: bracket every `every`-th shared-weights all-reduce with an event pair on the current stream
+        (what the step's stream waits for: the collective as the step sees it, exposed). every = 0: stop and return
+        {"samples", "mean_us", "max_us"} of what was recorded (None if nothing was)."""
+        if every > 0:
+            self.allreduce_timing = {"every": int(every), "events": []}
+            return None
+        timing, self.allreduce_timing = self.allreduce_timing, None
+        if not timing or not timing["events"]:
+            return None
+        torch.cuda.synchronize(self.W.device)
+        us = [a.elapsed_time(b) * 1e3 for a, b in timing["events"]]
+        return {"samples": len(us), "mean_us": sum(us) / len(us), "max_us": max(us)}
 
     # ------------------------------------------------------------------ checkpoint / resume (SURVEY §5)
     _STATE_FIELDS = ("x", "y", "vx", "vy", "option_id", "opt_steps", "ep_steps", "qcache", "action", "reward", "done")

@@ -290,6 +290,24 @@ class ScgContext:
         self._chk(w, torch.float32, n_fit * CLF_STRIDE, "w")
         self._call("scg_fit_initiation", n_fit, _ptr(xy), _ptr(label), _ptr(offsets), _ptr(w), iters,
                    C.c_float(lr), C.c_float(l2), self._stream())
+        # a fit whose workgroups could not run together gives up on the device (rows of w untouched) and says so in the
+        # ctx's status word: the outer loop is about to act on these classifiers, so wait and look now (rare call)
+        self.async_status(synchronize=True)
+
+    # ------------------------------------------------------------------ asynchronous failures (include/scg_abi.h)
+    def async_status(self, synchronize: bool = False) -> int:
+        """Raise ScgError if a kernel launched earlier gave up on the device (sticky until clear_async_error);
+        returns the raw status word otherwise (0)."""
+        word = C.c_uint32(0)
+        self._call("scg_async_status", self._stream(), 1 if synchronize else 0, C.byref(word))
+        return int(word.value)
+
+    def clear_async_error(self) -> None:
+        self._call("scg_clear_async_error")
+
+    def set_fit_timeout(self, seconds: float) -> None:
+        """How long fit_initiation waits for a workgroup that is not running yet before it abandons that fit."""
+        self._call("scg_set_fit_timeout", C.c_double(seconds))
 
 
 class EnvState:

@@ -33,6 +33,7 @@
 
 using namespace scg;
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // LDS map of the step kernel (bytes). 8 wavefronts per workgroup, two workgroups per CU (80 KB each).
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
     const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
     const int rowy = (int)blockIdx.y - R.n_vf;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (k < 0) {
         const int row = rowy * (int)gridDim.x + blockIdx.x;                 // one row per workgroup (waves 0..3): a row
         commit_and_place_row(R, row, wave, lane, s_x);                      // moves ~25 KB, so spread them over the CUs
@@ -1171,8 +1172,12 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     }
     const int i4 = blockIdx.x * 64 + lane;
     const bool live = i4 < RED_COLS;
-    const size_t stride4 = (size_t)R.n_vf * RED_COLS;
-    const float4 *p = reinterpret_cast<const float4 *>(R.slabs) + (size_t)k * RED_COLS + (live ? i4 : 0);
+    // slab addresses = wave-uniform base (block, value function: SGPRs) + this lane's column offset (one VGPR): sixteen
+    // 64-bit per-lane pointers would not fit beside the sixteen float4 in flight (the kernel ran at the 128-VGPR cap
+    // with 8 spilled registers and a vmcnt(0) in front of the first slab load)
+    const size_t slab_stride = (size_t)R.n_vf * RED_COLS * sizeof(float4);
+    const char *slab_k = reinterpret_cast<const char *>(R.slabs) + (size_t)k * RED_COLS * sizeof(float4);
+    const unsigned col_off = (unsigned)(live ? i4 : 0) * (unsigned)sizeof(float4);
     const int nseg = (R.nblk + SEG - 1) / SEG;
     float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int nk = 0;
@@ -1192,15 +1197,22 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
         float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (mask) {
-            float4 v[SEG];
+            // buffer loads: descriptor = the segment's first slab of this value function (SGPRs), scalar offset = slab u,
+            // vector offset = the lane's column
+            const __amdgpu_buffer_rsrc_t seg = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(slab_k + (size_t)b0 * slab_stride), 0, 0x7fffffff, 0x00020000);
+            u4v v[SEG];
 #pragma unroll
             for (int u = 0; u < SEG; ++u) {
-                v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if ((mask >> u) & 1u) v[u] = p[(size_t)(b0 + u) * stride4];
+                v[u] = (u4v){0u, 0u, 0u, 0u};
+                if ((mask >> u) & 1u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(seg, (int)col_off, (int)(u * (unsigned)slab_stride), 0);
             }
 #pragma unroll
             for (int u = 0; u < SEG; ++u) {
-                if ((mask >> u) & 1u) { T.x = T.x + v[u].x; T.y = T.y + v[u].y; T.z = T.z + v[u].z; T.w = T.w + v[u].w; }
+                if ((mask >> u) & 1u) {
+                    T.x = T.x + __uint_as_float(v[u][0]); T.y = T.y + __uint_as_float(v[u][1]);
+                    T.z = T.z + __uint_as_float(v[u][2]); T.w = T.w + __uint_as_float(v[u][3]);
+                }
             }
         }
         s_T[wave][lane] = T;
@@ -1467,7 +1479,8 @@ constexpr int FIT_STRIDE = FIT_G * FIT_T;
 
 __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8_t *label, const int32_t *offsets,
                                                     float *w, int iters, float lr, float l2, int q0,
-                                                    unsigned long long *part) {
+                                                    unsigned long long *part, unsigned long long timeout_ticks,
+                                                    uint32_t *async_word) {
     __shared__ float sw[8];
     __shared__ float swave[FIT_T / 64][6];
     __shared__ int s_abort;
@@ -1533,10 +1546,20 @@ __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8
             unsigned long long v = tag;
             if (lane < 6 * FIT_G) {                          // lane -> (workgroup lane / 6, component lane % 6)
                 const unsigned long long *src = &buf[(lane / 6) * 8 + lane % 6];
+                // The option's FIT_G workgroups must all be running for this to complete. A plain launch (and a
+                // cooperative one: MI355X_MICROARCH.md, residency) promises that only on an otherwise idle card: another
+                // stream or process may hold CUs. A late partner is waited for on the 100 MHz wall clock — seconds,
+                // not a spin count — and a partner that never shows up ABORTS the fit: weights left as they were,
+                // SCG_ASYNC_FIT_TIMEOUT raised in the ctx's host-visible status word (scg_async_status).
+                unsigned long long t0 = 0;
                 int spins = 0;
                 while (((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (tag >> 32)) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 22)) { s_abort = 1; break; }      // never reached with co-resident workgroups
+                    if ((++spins & 255) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > timeout_ticks) { s_abort = 1; break; }
+                    }
                 }
             }
             const float val = __uint_as_float((unsigned)v);
@@ -1553,7 +1576,12 @@ __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8
         if (s_abort) break;
     }
     __syncthreads();
-    if (j == 0 && tid < 6) w[CLF_STRIDE * q + tid] = s_abort ? __uint_as_float(0x7fc00000u) : sw[tid];
+    if (s_abort) {                                        // no silent NaN row: w keeps its old value, the host is told
+        if (tid == 0 && async_word)
+            __hip_atomic_fetch_or(async_word, SCG_ASYNC_FIT_TIMEOUT | (0x100u << (q & 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (j == 0 && tid < 6) w[CLF_STRIDE * q + tid] = sw[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1568,6 +1596,9 @@ struct scg_ctx {
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
     unsigned long long *d_fit_part;   // fit_kernel: tagged workgroup partials [FIT_BATCH][2][FIT_G][8]
+    uint32_t *h_async;             // pinned, device-visible status word: kernels that give up OR their reason into it
+    uint32_t *d_async;             // ... its device address
+    double fit_timeout_s;          // how long fit_kernel waits for a workgroup that is not running yet
     float4 *d_outrec;              // [nblk * BLOCK_ENVS][4] per-position step results (td_kernel -> commit_row)
     int32_t *d_invperm;            // [n_envs] position of each env in d_perm
     int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
@@ -1614,6 +1645,22 @@ static int fail(scg_ctx *ctx, int code, const char *msg) {
     return code;
 }
 
+// Sticky device-side failures (include/scg_abi.h, "asynchronous failures"): checked before every launch.
+static int decode_async(uint32_t word, char *buf, size_t n) {
+    if (word == 0) { if (buf && n) buf[0] = 0; return SCG_OK; }
+    if (buf && n) {
+        if (word & SCG_ASYNC_FIT_TIMEOUT)
+            snprintf(buf, n, "an earlier scg_fit_initiation gave up (problem mask 0x%x): its workgroups did not become "
+                     "co-resident within the fit timeout (card shared with other work?); the affected classifier rows were "
+                     "left unchanged. scg_clear_async_error() re-arms the context", (word >> 8) & 0xffffu);
+        else
+            snprintf(buf, n, "unknown asynchronous device status 0x%x", word);
+    }
+    return SCG_ERR_ASYNC;
+}
+static int async_pending(scg_ctx *c);
+#define SCG_CHECK_ASYNC(c) do { if (async_pending(c)) return SCG_ERR_ASYNC; } while (0)
+
 // Every entry point that touches the device runs with the ctx's device current and leaves the caller's current
 // device as it found it (a multi-GPU caller that forgot torch.cuda.set_device would otherwise launch on the
 // wrong card, against buffers owned by another GPU).
@@ -1636,9 +1683,51 @@ struct DeviceGuard {
     DeviceGuard dev_guard_((c)->cfg.device);                                                     \
     if (!dev_guard_.ok) return fail((c), SCG_ERR_HIP, what ": cannot make the context's device current")
 
+static int async_pending(scg_ctx *c) {
+    if (!c || !c->h_async) return 0;
+    const uint32_t w = *reinterpret_cast<volatile uint32_t *>(c->h_async);
+    if (w == 0) return 0;
+    decode_async(w, c->err, sizeof(c->err));
+    return 1;
+}
+
 extern "C" {
 
 int scg_abi_version(void) { return SCG_ABI_VERSION; }
+
+int scg_decode_async_word(uint32_t word, char *buf, int32_t buf_len) {
+    return decode_async(word, buf, buf_len > 0 ? (size_t)buf_len : 0);
+}
+
+int scg_async_status(scg_ctx *c, void *stream, int32_t synchronize, uint32_t *word_out) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_async_status: null ctx");
+    if (synchronize) {
+        SCG_ON_DEVICE(c, "scg_async_status");
+        SCG_HIP(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    }
+    const uint32_t w = c->h_async ? *reinterpret_cast<volatile uint32_t *>(c->h_async) : 0u;
+    if (word_out) *word_out = w;
+    return decode_async(w, c->err, sizeof(c->err));
+}
+
+int scg_clear_async_error(scg_ctx *c) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_clear_async_error: null ctx");
+    if (c->h_async) *reinterpret_cast<volatile uint32_t *>(c->h_async) = 0u;
+    return SCG_OK;
+}
+
+int scg_set_fit_timeout(scg_ctx *c, double seconds) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_fit_timeout: null ctx");
+    if (!(seconds >= 0.0) || seconds > 3600.0) return fail(c, SCG_ERR_INVALID, "scg_set_fit_timeout: seconds must be in [0, 3600]");
+    c->fit_timeout_s = seconds;
+    return SCG_OK;
+}
+
+int scg_debug_raise_async(scg_ctx *c, uint32_t word) {
+    if (!c || !c->h_async) return fail(c, SCG_ERR_INVALID, "scg_debug_raise_async: null ctx");
+    *reinterpret_cast<volatile uint32_t *>(c->h_async) |= word;
+    return SCG_OK;
+}
 
 int scg_block_envs(void) { return BLOCK_ENVS; }
 
@@ -1649,6 +1738,7 @@ const char *scg_strerror(int status) {
         case SCG_ERR_NO_DEVICE: return "no usable HIP device";
         case SCG_ERR_HIP: return "HIP runtime error";
         case SCG_ERR_STATE: return "call order / state error";
+        case SCG_ERR_ASYNC: return "an earlier launch failed on the device";
         default: return "unknown status";
     }
 }
@@ -1688,6 +1778,9 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_fit_part, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(unsigned long long)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_async), 64, hipHostMallocMapped) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        *c->h_async = 0u;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_async), c->h_async, 0) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_outrec, (size_t)c->nblk * BLOCK_ENVS * 4 * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_invperm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         {
@@ -1718,6 +1811,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
     c->parents = 0;
     for (int k = 1; k < MAX_VF; ++k) c->parents |= (uint32_t)(k - 1) << (3 * k);      // chain: 1 -> goal, k -> k-1
     c->G_out = c->d_G; c->nk_out = c->d_nk;
+    c->fit_timeout_s = 2.0;
     *out = c;
     return SCG_OK;
 }
@@ -1728,6 +1822,7 @@ int scg_destroy(scg_ctx *c) {
     (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]); (void)hipFree(c->d_outrec); (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
     (void)hipFree(c->d_fit_part);
+    if (c->h_async) (void)hipHostFree(c->h_async);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -1841,6 +1936,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     if (!x || !y || !vx || !vy || !option_id || !opt_steps || !ep_steps || !qcache || !action || !reward ||
         !done || !W || !clf)
         return fail(c, SCG_ERR_INVALID, "scg_step: null array argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_step");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     StepArgs A;
@@ -1944,6 +2040,7 @@ int scg_collect_examples(scg_ctx *c, uint32_t event_bits, uint8_t *prev_in, int3
     if (!c->ring_x || !c->events) return fail(c, SCG_ERR_STATE, "scg_collect_examples: trace buffers are not attached");
     if (!event_bits || l_pos < 0 || l_neg < 0 || l_pos + l_neg < 1 || !ex_xy || !ex_label || !count || cap < 0)
         return fail(c, SCG_ERR_INVALID, "scg_collect_examples: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_collect_examples");
     hipLaunchKernelGGL(collect_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), c->cfg.n_envs,
                        c->events, prev_in, event_bits, c->ring_x, c->ring_y, c->ring_len, c->ev_len, l_pos, l_neg, ex_xy,
@@ -1969,6 +2066,7 @@ int scg_harvest(scg_ctx *c, int32_t n_sel, const int32_t *sel_env, const float *
     if (n_sel < 0 || l_pos < 0 || l_neg < 0 || l_pos + l_neg < 1 || ring_len < 1 || (ring_len & (ring_len - 1)) ||
         !sel_env || !ring_x || !ring_y || !ev_len || !out_xy || !out_label)
         return fail(c, SCG_ERR_INVALID, "scg_harvest: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_harvest");
     if (n_sel == 0) return SCG_OK;
     const long long total = (long long)n_sel * (l_pos + l_neg);
@@ -2029,6 +2127,7 @@ int scg_set_grad_buffer_packed(scg_ctx *c, float *G_packed) {
 int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *stream) {
     if (!c || !W || !G_packed) return fail(c, SCG_ERR_INVALID, "scg_apply_update_packed: null argument");
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update_packed: scg_set_map has not been called (scale table)");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_apply_update_packed");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G_packed,
@@ -2040,6 +2139,7 @@ int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *s
 int scg_apply_update(scg_ctx *c, float *W, const float *G, const int32_t *n_k, void *stream) {
     if (!c || !W || !G || !n_k) return fail(c, SCG_ERR_INVALID, "scg_apply_update: null argument");
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update: scg_set_map has not been called (scale table)");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_apply_update");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G, n_k,
@@ -2054,6 +2154,7 @@ int scg_pinball_step(scg_ctx *c, int32_t n, float *x, float *y, float *vx, float
     if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_pinball_step: scg_set_map has not been called");
     if (n < 0 || !x || !y || !vx || !vy || !action || !reward || !goal)
         return fail(c, SCG_ERR_INVALID, "scg_pinball_step: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_pinball_step");
     if (n == 0) return SCG_OK;
     hipLaunchKernelGGL(pinball_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -2066,6 +2167,7 @@ int scg_fourier_features(scg_ctx *c, int32_t n, const float *x, const float *y, 
                          const float *vy, float *phi, void *stream) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_fourier_features: null ctx");
     if (n < 0 || !x || !y || !vx || !vy || !phi) return fail(c, SCG_ERR_INVALID, "scg_fourier_features: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_fourier_features");
     if (n == 0) return SCG_OK;
     const int grid = n < 8192 ? n : 8192;
@@ -2079,6 +2181,7 @@ int scg_q_values(scg_ctx *c, int32_t n, const float *x, const float *y, const fl
                  const float *Wk, float *q, void *stream) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_q_values: null ctx");
     if (n < 0 || !x || !y || !vx || !vy || !Wk || !q) return fail(c, SCG_ERR_INVALID, "scg_q_values: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_q_values");
     if (n == 0) return SCG_OK;
     StepArgs A;
@@ -2101,6 +2204,7 @@ int scg_q_update(scg_ctx *c, int32_t n, int32_t k, const float *x, const float *
     if (k < 0 || k >= c->n_vf) return fail(c, SCG_ERR_INVALID, "scg_q_update: VF index out of range");
     if (!x || !y || !vx || !vy || !action || !r || !cont || !xn || !yn || !vxn || !vyn || !W)
         return fail(c, SCG_ERR_INVALID, "scg_q_update: null array argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_q_update");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblk = (n + BLOCK_ENVS - 1) / BLOCK_ENVS;
@@ -2123,6 +2227,7 @@ int scg_classifier_predict(scg_ctx *c, int32_t n, const float *x, const float *y
                            void *stream) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_classifier_predict: null ctx");
     if (n < 0 || !x || !y || !w8 || !out) return fail(c, SCG_ERR_INVALID, "scg_classifier_predict: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_classifier_predict");
     if (n == 0) return SCG_OK;
     hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
@@ -2136,6 +2241,7 @@ int scg_fit_initiation(scg_ctx *c, int32_t n_fit, const float *xy, const uint8_t
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_fit_initiation: null ctx");
     if (n_fit < 0 || iters < 0 || !xy || !label || !offsets || !w)
         return fail(c, SCG_ERR_INVALID, "scg_fit_initiation: bad argument");
+    SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_fit_initiation");
     if (n_fit == 0 || iters == 0) return SCG_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -2143,7 +2249,7 @@ int scg_fit_initiation(scg_ctx *c, int32_t n_fit, const float *xy, const uint8_t
         const int nb = n_fit - q0 < FIT_BATCH ? n_fit - q0 : FIT_BATCH;
         SCG_HIP(c, hipMemsetAsync(c->d_fit_part, 0, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(unsigned long long), s));   // tags of a past call
         hipLaunchKernelGGL(fit_kernel, dim3(FIT_G, nb), dim3(FIT_T), 0, s, xy, label, offsets, w, iters, lr, l2, q0,
-                           c->d_fit_part);
+                           c->d_fit_part, (unsigned long long)(c->fit_timeout_s * 1e8), c->d_async);
         SCG_HIP(c, hipGetLastError());
     }
     return SCG_OK;

@@ -64,7 +64,8 @@ def test_every_ctx_entry_point_rejects_a_null_ctx(pkg):
     SCG_ERR_INVALID and leaves a message behind (runs without a GPU)."""
     from skill_chaining_with_graphs_amd import _lib
     lib = pkg.load_library()
-    skip = {"scg_abi_version", "scg_block_envs", "scg_strerror", "scg_last_error", "scg_create", "scg_destroy"}
+    skip = {"scg_abi_version", "scg_block_envs", "scg_strerror", "scg_last_error", "scg_create", "scg_destroy",
+            "scg_decode_async_word"}
     for name, (res, args) in _lib._SIGS.items():
         if name in skip:
             continue
@@ -72,3 +73,18 @@ def test_every_ctx_entry_point_rejects_a_null_ctx(pkg):
         zeros = [None if (a is C.c_void_p or hasattr(a, "contents")) else a(0) for a in args]
         assert getattr(lib, name)(*zeros) == -1, name
         assert lib.scg_last_error(None), name
+
+
+def test_async_status_word_decoding(pkg):
+    """The mapping from the device-written status word to a status and a message is pure host code (the error path of a
+    fit that gave up on the device, include/scg_abi.h "asynchronous failures"): it runs here without a GPU."""
+    lib = pkg.load_library()
+    buf = C.create_string_buffer(256)
+    assert lib.scg_decode_async_word(0, buf, 256) == 0 and buf.value == b""
+    rc = lib.scg_decode_async_word(0x1 | (0x100 << 3), buf, 256)
+    assert rc == -5 and b"scg_fit_initiation" in buf.value and b"0x8" in buf.value and b"unchanged" in buf.value
+    assert lib.scg_decode_async_word(0x80000000, buf, 256) == -5 and b"unknown" in buf.value
+    assert lib.scg_decode_async_word(0x1, None, 0) == -5              # no buffer: status only
+    small = C.create_string_buffer(8)
+    assert lib.scg_decode_async_word(0x1, small, 8) == -5 and len(small.value) == 7      # truncated, terminated
+    assert lib.scg_strerror(-5).startswith(b"an earlier launch")

@@ -1,0 +1,100 @@
+"""Failure paths a careful user would fall into: a kernel that gives up on the device must say so —
+never a silent wrong result behind SCG_OK."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, make_pair
+from skill_chaining_with_graphs_amd._lib import ScgError
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit_problem(seed, sizes):
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    xy = rng.random((off[-1], 2)).astype(np.float32)
+    lab = (((xy[:, 0] - 0.5) ** 2 + (xy[:, 1] - 0.45) ** 2) < 0.3 ** 2).astype(np.uint8)
+    w = (rng.standard_normal((len(sizes), 8)) * 0.05).astype(np.float32)
+    return xy, lab, off, w
+
+
+def test_async_error_is_sticky_refuses_every_launch_and_clears():
+    ctx, orc, m = make_pair("pinball_simple", 256)
+    assert ctx.async_status(synchronize=True) == 0
+    ctx.lib.scg_debug_raise_async(ctx._ctx, C.c_uint32(0x1 | (0x100 << 2)))     # what fit_kernel writes when it gives up
+    x = torch.rand(256, device="cuda:0")
+    with pytest.raises(ScgError, match="scg_fit_initiation gave up"):
+        ctx.async_status()
+    with pytest.raises(ScgError, match="earlier launch failed"):
+        ctx.classifier_predict(x, x.clone(), torch.zeros(8, device="cuda:0"))
+    with pytest.raises(ScgError, match="problem mask 0x4"):
+        ctx.features([x, x.clone(), x.clone(), x.clone()])
+    xy, lab, off, w = _fit_problem(1, [500])
+    w_d = dev(w.copy())
+    with pytest.raises(ScgError):
+        ctx.fit_initiation(dev(xy).view(-1), dev(lab), dev(off), w_d.view(-1), iters=5)
+    assert np.array_equal(w_d.cpu().numpy(), w)                                    # nothing ran
+    ctx.clear_async_error()
+    assert ctx.async_status(synchronize=True) == 0
+    ctx.fit_initiation(dev(xy).view(-1), dev(lab), dev(off), w_d.view(-1), iters=5, lr=2.0, l2=1e-3)
+    orc.fit_initiation(xy, lab, off, w, iters=5, lr=2.0, l2=1e-3)
+    assert np.array_equal(w_d.cpu().numpy(), w)
+
+
+def _busy_stream(ms_target=150):
+    """A side stream that keeps every CU busy for a while (large f32 GEMMs from the vendor library)."""
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda:0")
+    b = torch.randn(4096, 4096, device="cuda:0")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(max(1, ms_target // 2)):          # ~1.5-2 ms each
+            a = (a @ b) * 1e-3
+    return side, a
+
+
+def test_fit_is_exact_while_another_stream_keeps_the_card_busy():
+    """The fit's eight workgroups per problem exchange partial sums every iteration and need to run together; with the
+    card shared they may start late. Late partners are waited for (wall clock), so the result is still bit-exact."""
+    ctx, orc, m = make_pair("pinball_simple", 256)
+    xy, lab, off, w = _fit_problem(2, [30000, 0, 7000, 1, 12000])
+    w_o = w.copy()
+    orc.fit_initiation(xy, lab, off, w_o, iters=60, lr=2.0, l2=1e-3)
+    xy_d, lab_d, off_d = dev(xy).view(-1), dev(lab), dev(off)
+    for rep in range(3):
+        side, keep = _busy_stream()
+        w_d = dev(w.copy())
+        ctx.fit_initiation(xy_d, lab_d, off_d, w_d.view(-1), iters=60, lr=2.0, l2=1e-3)     # waits for its own stream + status
+        assert np.array_equal(w_d.cpu().numpy(), w_o), rep
+        side.synchronize()
+    assert ctx.async_status(synchronize=True) == 0
+
+
+def test_fit_with_no_patience_is_exact_or_reports_and_leaves_the_rows_alone():
+    """scg_set_fit_timeout(0): a partner that is not there at once makes the problem give up. Whatever happens, a row of w
+    is either the exact result or untouched, and an abandoned fit raises — never SCG_OK over a half-done row."""
+    ctx, orc, m = make_pair("pinball_simple", 256)
+    xy, lab, off, w = _fit_problem(3, [20000, 9000, 4000])
+    w_o = w.copy()
+    orc.fit_initiation(xy, lab, off, w_o, iters=40, lr=2.0, l2=1e-3)
+    ctx.set_fit_timeout(0.0)
+    side, keep = _busy_stream()
+    w_d = dev(w.copy())
+    try:
+        ctx.fit_initiation(dev(xy).view(-1), dev(lab), dev(off), w_d.view(-1), iters=40, lr=2.0, l2=1e-3)
+        gave_up = False
+    except ScgError as e:
+        gave_up = True
+        assert "gave up" in str(e)
+    side.synchronize()
+    torch.cuda.synchronize()
+    got = w_d.cpu().numpy()
+    for q in range(3):
+        assert np.array_equal(got[q], w_o[q]) or (gave_up and np.array_equal(got[q], w[q])), q
+    if not gave_up:
+        assert np.array_equal(got, w_o)
+    ctx.clear_async_error()
+    ctx.set_fit_timeout(2.0)
