@@ -1367,58 +1367,99 @@ __global__ __launch_bounds__(256) void harvest_kernel(int n_sel, const int32_t *
     out_label[t] = ok ? (j < l_pos ? 1 : 0) : 255;
 }
 
-// SPEC §7 device-side trigger + harvest in one launch (no host round trip per step): ONE workgroup walks the envs in
-// env order, 1024 at a time. An env is selected when (events & bits) != 0 — with `prev_in` given, only on the step it
-// ENTERS that state (prev_in is updated). A selected env contributes its v = min(L, ev_len, ring_len) most recent ring
-// states (age j < l_pos: label 1, else 0), appended behind the *count examples the buffer already holds, in env order,
-// ages ascending; what does not fit into `cap` is dropped. Ordered compaction = ballots + popcounts inside a wave, a
-// 16-entry scan across the waves, a running offset across the chunks: deterministic.
-__global__ __launch_bounds__(1024) void collect_kernel(int n, const uint8_t *events, uint8_t *prev_in, uint32_t bits,
-                                                       const float *ring_x, const float *ring_y, int ring_len,
-                                                       const int32_t *ev_len, int l_pos, int l_neg, float *ex_xy,
-                                                       uint8_t *ex_label, int32_t *count, int cap) {
-    __shared__ int s_wsum[16];
-    __shared__ int s_base;
+// SPEC §7 device-side trigger + harvest (no host round trip per step), two small launches over rows of COL_ROW envs.
+// An env is selected when (events & bits) != 0 — with `prev_in` given, only on the step it ENTERS that state (prev_in is
+// updated). A selected env contributes its v = min(L, ev_len, ring_len) most recent ring states (age j < l_pos: label 1,
+// else 0), appended behind the *count examples the buffer already holds, in env order, ages ascending; what does not fit
+// into `cap` is dropped.
+//   collect_count_kernel    row totals of v (integer sums: order-free) -> rowsum[row]; the buffer's fill level -> rowsum[nrows]
+//   collect_scatter_kernel  offset of a row = fill level + totals of the rows before it; inside a row ballots + popcounts
+//                           per wave and a 16-entry scan across the waves; a selected env's examples are gathered by the
+//                           lanes of its wave together (lane j = age j), not one after another by the env's own lane
+// Deterministic: every position is a prefix sum of integers in env order. (Round 2 walked the envs with ONE workgroup,
+// 1024 at a time behind three barriers each: 64 dependent memory round trips per step-batch at the bench size.)
+constexpr int COL_ROW = 1024;
+
+__device__ __forceinline__ int collect_v(int e, int n, const uint8_t *events, const uint8_t *prev_in, uint32_t bits,
+                                         const int32_t *ev_len, int ring_len, int L, bool &in_out) {
+    in_out = false;
+    if (e >= n) return 0;
+    const bool in = (events[e] & bits) != 0;
+    in_out = in;
+    const bool hit = prev_in ? (in && !prev_in[e]) : in;
+    return hit ? min(min(L, ev_len[e]), ring_len) : 0;
+}
+
+__global__ __launch_bounds__(COL_ROW) void collect_count_kernel(int n, const uint8_t *events, const uint8_t *prev_in,
+                                                                uint32_t bits, const int32_t *ev_len, int ring_len, int L,
+                                                                int32_t *rowsum, int nrows, const int32_t *count) {
+    __shared__ int s_w[COL_ROW / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = l_pos + l_neg;
-    if (tid == 0) s_base = *count;
+    bool in;
+    int v = collect_v(blockIdx.x * COL_ROW + tid, n, events, prev_in, bits, ev_len, ring_len, L, in);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) s_w[wave] = v;
     __syncthreads();
-    for (int e0 = 0; e0 < n; e0 += 1024) {
-        const int e = e0 + tid;
-        int v = 0;
-        if (e < n) {
-            const bool in = (events[e] & bits) != 0;
-            bool hit = in;
-            if (prev_in) { hit = in && !prev_in[e]; prev_in[e] = in ? 1 : 0; }
-            if (hit) v = min(min(L, ev_len[e]), ring_len);
-        }
-        // exclusive prefix of v inside the wave (6 shuffle steps), then across the 16 waves
-        int incl = v;
+    if (tid == 0) {
+        int t = 0;
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const int t = __shfl_up(incl, m, 64);
-            if (lane >= m) incl += t;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
+        for (int w2 = 0; w2 < COL_ROW / 64; ++w2) t += s_w[w2];
+        rowsum[blockIdx.x] = t;
+        if (blockIdx.x == 0) rowsum[nrows] = *count;
+    }
+}
+
+__global__ __launch_bounds__(COL_ROW) void collect_scatter_kernel(int n, const uint8_t *events, uint8_t *prev_in, uint32_t bits,
+                                                                  const float *ring_x, const float *ring_y, int ring_len,
+                                                                  const int32_t *ev_len, int l_pos, int l_neg, float *ex_xy,
+                                                                  uint8_t *ex_label, int32_t *count, int cap,
+                                                                  const int32_t *rowsum, int nrows) {
+    __shared__ int s_w[COL_ROW / 64], s_pre[COL_ROW / 64], s_tot[COL_ROW / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = blockIdx.x;
+    const int L = l_pos + l_neg;
+    const int e = row * COL_ROW + tid;
+    bool in;
+    const int v = collect_v(e, n, events, prev_in, bits, ev_len, ring_len, L, in);
+    const int evl = v > 0 ? ev_len[e] : 0;
+    if (prev_in && e < n) prev_in[e] = in ? 1 : 0;        // only this thread reads or writes this byte in this launch
+    // totals of the rows before this one (and of all rows, for the new fill level)
+    int before = 0, all = 0;
+    for (int r = tid; r < nrows; r += COL_ROW) { const int t = rowsum[r]; all += t; if (r < row) before += t; }
+    int incl = v;                                          // inclusive prefix of v inside the wave
 #pragma unroll
-        for (int w2 = 0; w2 < 16; ++w2) { const int t = s_wsum[w2]; if (w2 < wave) woff += t; tot += t; }
-        const int base = s_base;
-        const int pos0 = base + woff + incl - v;
-        for (int j = 0; j < v; ++j) {
-            const int pos = pos0 + j;
+    for (int m = 1; m < 64; m <<= 1) {
+        const int t = __shfl_up(incl, m, 64);
+        if (lane >= m) incl += t;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { before += __shfl_xor(before, m, 64); all += __shfl_xor(all, m, 64); }
+    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0) { s_pre[wave] = before; s_tot[wave] = all; }
+    __syncthreads();
+    int base = rowsum[nrows], woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < COL_ROW / 64; ++w2) {
+        base += s_pre[w2]; total += s_tot[w2];
+        if (w2 < wave) woff += s_w[w2];
+    }
+    if (row == 0 && tid == 0) *count = min(rowsum[nrows] + total, cap);
+    const int pos0 = base + woff + incl - v;
+    // the wave's selected envs one after another, the examples of one env on as many lanes
+    uint64_t hits = __ballot(v > 0);
+    while (hits) {
+        const int src = (int)__builtin_ctzll(hits);
+        hits &= hits - 1;
+        const int he = __shfl(e, src, 64), hv = __shfl(v, src, 64), hp = __shfl(pos0, src, 64), hl = __shfl(evl, src, 64);
+        for (int j = lane; j < hv; j += 64) {
+            const int pos = hp + j;
             if (pos < cap) {
-                const size_t row = (size_t)((ev_len[e] - 1 - j) & (ring_len - 1)) * n + e;
-                ex_xy[2 * (size_t)pos] = ring_x[row]; ex_xy[2 * (size_t)pos + 1] = ring_y[row];
+                const size_t rrow = (size_t)((hl - 1 - j) & (ring_len - 1)) * n + he;
+                ex_xy[2 * (size_t)pos] = ring_x[rrow]; ex_xy[2 * (size_t)pos + 1] = ring_y[rrow];
                 ex_label[pos] = j < l_pos ? 1 : 0;
             }
         }
-        __syncthreads();
-        if (tid == 0) s_base = min(base + tot, cap);
-        __syncthreads();
     }
-    if (tid == 0) *count = s_base;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1595,6 +1636,7 @@ struct scg_ctx {
     float *d_edges, *d_starts, *d_scale;
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
+    int32_t *d_collect_rows;       // scg_collect_examples: per-row totals [rows of COL_ROW envs] + the buffer's fill level
     unsigned long long *d_fit_part;   // fit_kernel: tagged workgroup partials [FIT_BATCH][2][FIT_G][8]
     uint32_t *h_async;             // pinned, device-visible status word: kernels that give up OR their reason into it
     uint32_t *d_async;             // ... its device address
@@ -1777,6 +1819,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_collect_rows, (size_t)((cfg->n_envs + COL_ROW - 1) / COL_ROW + 1) * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_fit_part, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(unsigned long long)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_async), 64, hipHostMallocMapped) != hipSuccess) { st = SCG_ERR_HIP; break; }
         *c->h_async = 0u;
@@ -1821,7 +1864,7 @@ int scg_destroy(scg_ctx *c) {
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
     (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]); (void)hipFree(c->d_outrec); (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
-    (void)hipFree(c->d_fit_part);
+    (void)hipFree(c->d_fit_part); (void)hipFree(c->d_collect_rows);
     if (c->h_async) (void)hipHostFree(c->h_async);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
@@ -2042,9 +2085,13 @@ int scg_collect_examples(scg_ctx *c, uint32_t event_bits, uint8_t *prev_in, int3
         return fail(c, SCG_ERR_INVALID, "scg_collect_examples: bad argument");
     SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_collect_examples");
-    hipLaunchKernelGGL(collect_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), c->cfg.n_envs,
-                       c->events, prev_in, event_bits, c->ring_x, c->ring_y, c->ring_len, c->ev_len, l_pos, l_neg, ex_xy,
-                       ex_label, count, cap);
+    const int nrows = (c->cfg.n_envs + COL_ROW - 1) / COL_ROW;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(collect_count_kernel, dim3(nrows), dim3(COL_ROW), 0, s, c->cfg.n_envs, c->events, prev_in, event_bits,
+                       c->ev_len, c->ring_len, l_pos + l_neg, c->d_collect_rows, nrows, count);
+    hipLaunchKernelGGL(collect_scatter_kernel, dim3(nrows), dim3(COL_ROW), 0, s, c->cfg.n_envs, c->events, prev_in, event_bits,
+                       c->ring_x, c->ring_y, c->ring_len, c->ev_len, l_pos, l_neg, ex_xy, ex_label, count, cap,
+                       c->d_collect_rows, nrows);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
