@@ -42,11 +42,13 @@ constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, o
 constexpr int OFF_Z1 = OFF_INT + 5 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
 // region R, used by one phase at a time:
 //   P, Z  : s[4][128], sn[4][128] (the envs' states) and the edge table [256][8]
-//   E, U1 : W_k staged in A-operand order (12 row tiles x 9 k-blocks x 64 lanes) + per wave CDk[36][16] + ABq[16][36]
+//   E, U1 : W_k staged in A-operand order (12 row tiles x 9 k-blocks x 64 lanes) + per wave CDk[36][16] + ABq[16][AS]
 //   U2    : PT[36][US], CDT[36][US] (one chunk of 64 padded slots = 128 K-steps)
 constexpr int W_FLOATS = 12 * 9 * 64;
 constexpr int W_TAIL = 12 * 2 * 64 * 4;                        // k-block 8 of every tile sits behind the two float4 groups
-constexpr int E_TAB_FLOATS = 36 * 16 + 16 * 36;
+constexpr int AS = 40;                                         // row stride of ABq (floats): 16-byte rows, and the ds_read_b128 of the
+                                                               // fold (16-lane groups mixing row groups g, g + 1) conflict-free: 36 gave 2-way
+constexpr int E_TAB_FLOATS = 36 * 16 + 16 * AS;
 constexpr int US = 132;                                        // row stride of the chunk tables (floats)
 constexpr int R_TAB = W_FLOATS;                                // private tables start behind the staged W_k
 constexpr int R_S = R_TAB, R_EDGES = R_TAB + 8 * BLOCK_ENVS;   // phases P / Z: inside the table area of waves 0..3 (the helper
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
     const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
     float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
-    const float *ab_lane = abq + n16 * 36 + 4 * g;
+    const float *ab_lane = abq + n16 * AS + 4 * g;
 
     // private tables of one 8-item column block: items lst[i0 .. i0 + cnt) (a short block repeats its last item),
     // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                abq[bcol * 36 + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * 36 + 6 * c + cp] = -ab[c].y;
+                abq[bcol * AS + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * AS + 6 * c + cp] = -ab[c].y;
                 cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
             }
         }
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
                     const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
                     const bool in = r0 >= 0 && r0 < 36;
-                    const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * 36 + (in ? r0 : 0));
+                    const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * AS + (in ? r0 : 0));
                     float xq = qs;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) xq = fmaf(c[v], ab4[v], xq);
