@@ -263,6 +263,206 @@ __device__ __forceinline__ float pinball_step_any(const float *edges, const uint
     return pinball_step<4>(edges, cellmask, ms, x, y, vx, vy, a, goal);
 }
 
+// ------------------------------------------------------------------ SPEC §1.3, a whole wavefront of envs at once
+// The per-lane form above walks every candidate edge of its env one after another, 20 times, and a wave is as slow as its
+// env with the most candidates: on the bench workload half the envs have no edge within reach at all, a third have two
+// or more, and every 32-lane wave held some of each (3 register slots + the overflow loop = ~110 vector instructions per
+// sub-step for everybody). Here the wave first settles the envs without candidates (free flight: 2 fmas + the goal test per
+// sub-step), then deals the (env, candidate edge) PAIRS of the others to its lanes — one intercept per lane and sub-step —
+// and combines the hits of an env's lanes (a run of <= PCAP consecutive lanes) with one ballot: count = popcount, first hit
+// = lowest set bit, i.e. the lowest edge index, as SPEC §1.3 asks. Same candidate set, same tests, same order of
+// operations per env: bit-identical to pinball_step(). Envs with more than PCAP candidates take the per-lane loop.
+constexpr int PCAP = 8;                        // candidate edges per env the pair form handles
+constexpr int PITEMS = 64 * PCAP + 64;         // pair slots per wave (a run never straddles a group of 64: up to 7 pad slots per group)
+
+template <int NW>
+__device__ __forceinline__ float pinball_step_wave(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
+                                                   bool valid, float &x, float &y, float &vx, float &vy, int a,
+                                                   bool &goal_out, uint32_t *items /* LDS [PITEMS], this wave's */,
+                                                   float *xs /* LDS [4][stride]: this wave's 64 slots start at xs */, int stride,
+                                                   uint8_t *gflag /* LDS [64], this wave's */) {
+    const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
+    const float4 *E4 = reinterpret_cast<const float4 *>(edges);
+    const int lane = threadIdx.x & 63;
+    if (a == 0) vx = vx + DV;
+    else if (a == 2) vx = vx - DV;
+    else if (a == 1) vy = vy + DV;
+    else if (a == 3) vy = vy - DV;
+    vx = fminf(fmaxf(vx, -VMAX), VMAX);
+    vy = fminf(fmaxf(vy, -VMAX), VMAX);
+    // candidate set (SPEC §1.3, last paragraph; same bound and same refinement as pinball_step)
+    const float spd = __builtin_sqrtf(fmaf(vy, vy, vx * vx));
+    const float rr = fmaf(1.10f, spd, 1.02f);
+    const float reach2 = ms.R2 * rr * rr;
+    const int cxi = min(max((int)(x * (float)CELL_G), 0), CELL_G - 1);
+    const int cyi = min(max((int)(y * (float)CELL_G), 0), CELL_G - 1);
+    const uint64_t *cm = cellmask + (size_t)(cyi * CELL_G + cxi) * 4;
+    uint64_t mask[NW];
+    int nc = 0;
+#pragma unroll
+    for (int g = 0; g < NW; ++g) {
+        uint64_t m = valid ? cm[g] : 0ull, keep = 0;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int j = g * 64 + b;
+            if (edge_d2(E4[2 * j], edges[8 * j + 4], x, y) <= reach2) { keep |= 1ull << b; ++nc; }
+        }
+        mask[g] = keep;
+    }
+    const float gx0 = x - ms.TX, gy0 = y - ms.TY;
+    const float gr = ms.TR + (rr - 1.0f) * ms.R;
+    const bool near_goal = valid && fmaf(gy0, gy0, gx0 * gx0) <= gr * gr;
+    const float h = ms.hstep;
+    bool goal = false;
+    // ---- envs without a candidate: free flight
+    if (__ballot(valid && nc == 0)) {
+        const bool wave_goal = __ballot(near_goal && nc == 0) != 0;
+        if (valid && nc == 0) {
+            for (int i = 0; i < 20; ++i) {
+                x = fmaf(vx, h, x); y = fmaf(vy, h, y);
+                if (wave_goal) {
+                    const float gx = x - ms.TX, gy = y - ms.TY;
+                    if (fmaf(gy, gy, gx * gx) < ms.TR2) { goal = true; break; }
+                }
+            }
+        }
+    }
+    // ---- envs with more candidates than the pair form takes: the per-lane loop over their mask
+    if (__ballot(nc > PCAP)) {
+        if (nc > PCAP) {
+            for (int i = 0; i < 20; ++i) {
+                x = fmaf(vx, h, x); y = fmaf(vy, h, y);
+                int nhit = 0, first = -1;
+#pragma unroll
+                for (int g = 0; g < NW; ++g) {
+                    uint64_t m = mask[g];
+                    while (m) {
+                        const int j = g * 64 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        if (intercept(E4[2 * j], edges[8 * j + 4], ms.R2, x, y, vx, vy)) { if (nhit == 0) first = j; ++nhit; }
+                    }
+                }
+                if (nhit == 1) {
+                    const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
+                    const float pr = fmaf(vy, uy, vx * ux);
+                    const float tp = pr + pr;
+                    const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
+                    vx = nvx; vy = nvy;
+                    if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
+                } else if (nhit > 1) {
+                    vx = -vx; vy = -vy;
+                }
+                const float gx = x - ms.TX, gy = y - ms.TY;
+                if (fmaf(gy, gy, gx * gx) < ms.TR2) { goal = true; break; }
+            }
+        }
+    }
+    // ---- the others: one lane per (env, candidate edge)
+    const bool par = nc >= 1 && nc <= PCAP;
+    if (__ballot(par)) {
+        const int cnt = par ? nc : 0;
+        int p = cnt;                                           // exclusive prefix of cnt over the lanes
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int t = __shfl_up(p, m, 64);
+            if (lane >= m) p += t;
+        }
+        int total = __shfl(p, 63, 64);
+        p -= cnt;
+        for (int bnd = 64; bnd < total; bnd += 64) {           // no run may straddle a group of 64 pair slots: push it to the next group
+            const uint64_t cross = __ballot(cnt > 0 && p < bnd && p + cnt > bnd);
+            if (cross) {
+                const int src = (int)__builtin_ctzll(cross);
+                const int shift = bnd - __shfl(p, src, 64);
+                if (lane >= src) p += shift;
+                total += shift;
+            }
+        }
+        for (int q = lane; q < PITEMS; q += 64) items[q] = 0xffffffffu;      // pad slots stay empty
+        if (par) {
+            xs[lane] = x; xs[stride + lane] = y; xs[2 * stride + lane] = vx; xs[3 * stride + lane] = vy;
+            int c = 0;
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                uint64_t m = mask[g];
+                while (m) {
+                    const int j = g * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    items[p + c] = (unsigned)lane | ((unsigned)j << 8) | ((unsigned)c << 16) | ((unsigned)cnt << 20) | (near_goal ? 1u << 24 : 0u);
+                    ++c;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int r0 = 0; r0 < total; r0 += 64) {
+            const unsigned it = items[r0 + lane];
+            const bool act = it != 0xffffffffu;
+            const int src = act ? (int)(it & 63u) : 0, j = act ? (int)((it >> 8) & 255u) : 0;
+            const int c = (int)((it >> 16) & 15u), n = (int)((it >> 20) & 15u);
+            const uint64_t seg = act ? (((1ull << n) - 1ull) << (lane - c)) : 0ull;
+            const bool wave_goal = __ballot(act && ((it >> 24) & 1u)) != 0;
+            float px = xs[src], py = xs[stride + src], pvx = xs[2 * stride + src], pvy = xs[3 * stride + src];
+            const float4 ea = E4[2 * j];
+            const float4 eb = E4[2 * j + 1];                   // inv_len2, ux, uy, pad
+            bool pg = false;
+            for (int i = 0; i < 20; ++i) {
+                if (!pg) { px = fmaf(pvx, h, px); py = fmaf(pvy, h, py); }
+                const bool hit = act && !pg && intercept(ea, eb.x, ms.R2, px, py, pvx, pvy);
+                const uint64_t hits = __ballot(hit);
+                if (hits) {                                     // wave-uniform
+                    const uint64_t mine = hits & seg;
+                    const int nhit = __popcll(mine);
+                    const int fl = mine ? (int)__builtin_ctzll(mine) : lane;
+                    const float ux = __shfl(eb.y, fl, 64), uy = __shfl(eb.z, fl, 64);      // the lowest edge index among the hits
+                    if (nhit == 1) {
+                        const float pr = fmaf(pvy, uy, pvx * ux);
+                        const float tp = pr + pr;
+                        const float nvx = fmaf(tp, ux, -pvx), nvy = fmaf(tp, uy, -pvy);
+                        pvx = nvx; pvy = nvy;
+                        if (i == 19) { px = fmaf(pvx, h, px); py = fmaf(pvy, h, py); }
+                    } else if (nhit > 1) {
+                        pvx = -pvx; pvy = -pvy;
+                    }
+                }
+                if (wave_goal) {
+                    const float gx = px - ms.TX, gy = py - ms.TY;
+                    if (act && !pg && fmaf(gy, gy, gx * gx) < ms.TR2) pg = true;
+                }
+                if (!__ballot(act && !pg)) break;               // every env of this round is in the goal
+            }
+            if (act && c == 0) {
+                xs[src] = px; xs[stride + src] = py; xs[2 * stride + src] = pvx; xs[3 * stride + src] = pvy;
+                gflag[src] = pg ? 1 : 0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (par) { x = xs[lane]; y = xs[stride + lane]; vx = xs[2 * stride + lane]; vy = xs[3 * stride + lane]; goal = gflag[lane] != 0; }
+    }
+    float reward;
+    if (goal) {
+        reward = 10000.0f;
+    } else {
+        vx = vx * DRAG; vy = vy * DRAG;
+        x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f);
+        reward = (a == 4) ? -1.0f : -5.0f;
+    }
+    goal_out = goal;
+    return reward;
+}
+
+__device__ __forceinline__ float pinball_step_wave_any(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
+                                                       bool valid, float &x, float &y, float &vx, float &vy, int a, bool &goal,
+                                                       uint32_t *items, float *xs, int stride, uint8_t *gflag) {
+    if (ms.n_edges <= 64) return pinball_step_wave<1>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, items, xs, stride, gflag);
+    if (ms.n_edges <= 128) return pinball_step_wave<2>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, items, xs, stride, gflag);
+    return pinball_step_wave<4>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, items, xs, stride, gflag);
+}
+
 // ------------------------------------------------------------------ SPEC §4.1
 __device__ __forceinline__ float clf_z(const float *w, float x, float y) {
     const float u = fmaf(x, 2.0f, -1.0f), v = fmaf(y, 2.0f, -1.0f);

@@ -36,6 +36,8 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
+constexpr int P_WAVES = BLOCK_ENVS / 64;      // phase P: one lane per env on full waves
+constexpr int HELPER0 = WAVES / 2;            // waves HELPER0.. work under phase P (learning steps)
 // LDS map of the step kernel (bytes). 8 wavefronts per workgroup, two workgroups per CU (80 KB each).
 constexpr int OFF_RC = 0;                                      // float r0,c0,ro,co (per env), rk,ck (per env, this pass) [128]
 constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia [128]
@@ -51,7 +53,7 @@ constexpr int AS = 40;                                         // row stride of 
 constexpr int E_TAB_FLOATS = 36 * 16 + 16 * AS;
 constexpr int US = 132;                                        // row stride of the chunk tables (floats)
 constexpr int R_TAB = W_FLOATS;                                // private tables start behind the staged W_k
-constexpr int R_S = R_TAB, R_EDGES = R_TAB + 8 * BLOCK_ENVS;   // phases P / Z: inside the table area of waves 0..3 (the helper
+constexpr int R_S = R_TAB, R_EDGES = R_TAB + 8 * BLOCK_ENVS, R_PITEMS = R_EDGES + MAX_EDGES * 8;   // phases P / Z: inside the table area of waves 0..3 (the helper
                                                                // waves 4..7 use region W and their own tables meanwhile)
 constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 constexpr int R_FLOATS = cmax3(W_FLOATS + WAVES * E_TAB_FLOATS, 2 * 36 * US, R_EDGES + MAX_EDGES * 8);
@@ -71,7 +73,7 @@ constexpr int LDS_BYTES = OFF_MISC + 128;
 #endif
 static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
 static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0 && (R_EDGES * 4) % 16 == 0, "LDS alignment");
-static_assert(8 * BLOCK_ENVS + MAX_EDGES * 8 <= 4 * E_TAB_FLOATS, "states + edges fit the table area of waves 0..3");
+static_assert(8 * BLOCK_ENVS + MAX_EDGES * 8 + P_WAVES * PITEMS <= HELPER0 * E_TAB_FLOATS, "states + edges + the physics pair lists fit the table area of the waves below the helpers");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_s = reinterpret_cast<float *>(smem + OFF_R) + R_S;        // [8][128]: s then sn   (region R, phases P and Z)
     float *s_edges = reinterpret_cast<float *>(smem + OFF_R) + R_EDGES;  // [n_edges][8]        (region R, phase P)
+    uint32_t *s_pitems = reinterpret_cast<uint32_t *>(smem + OFF_R) + R_PITEMS;   // [P_WAVES][PITEMS] (env, edge) pairs of the physics
     float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
     float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
     float *s_rk = s_co + BLOCK_ENVS, *s_ck = s_rk + BLOCK_ENVS;       // reward / continuation of the pass's value function
@@ -358,17 +361,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
 
     // ------------------------------------------------------------------ phase P
-    if (helpers && wave < BLOCK_ENVS / 32) __builtin_amdgcn_s_setprio(2);   // phase P is the critical path: its waves issue
-                                                                             // ahead of the helper waves (which have slack)
-    if (wave < BLOCK_ENVS / 32 && lane < 32) {        // 4 waves x 32 lanes (64-lane waves measured slower: 22.1k vs 18.8k
-        const int i = wave * 32 + lane;               // cycles for the physics — more divergence per wave)
-        const int e = (MODE == MODE_FUSED && A.perm && i < nb) ? A.perm[e0 + i] : e0 + i;
+    if (helpers && wave < P_WAVES) __builtin_amdgcn_s_setprio(2);   // phase P is the critical path: its waves issue
+                                                                     // ahead of the helper waves (which have slack)
+    if (wave < P_WAVES) {                             // one lane per env on P_WAVES full waves; the physics deals (env, edge)
+        const int i = tid;                            // pairs to the lanes of the same wave (pinball_step_wave)
+        const bool valid = i < nb;
+        const int e = (MODE == MODE_FUSED && A.perm && valid) ? A.perm[e0 + i] : e0 + i;
         s_env[i] = e;
-        if (i < nb) {
-            if (MODE == MODE_FUSED) {
+        if (MODE == MODE_FUSED) {
+            uint32_t u[4] = {0u, 0u, 0u, 0u};
+            int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
+            float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
+            if (valid) {
                 // act (SPEC §2, §4.3)
                 const uint64_t g = (uint64_t)(A.env_base + e);
-                uint32_t u[4];
                 philox4x32_10((uint32_t)g, (uint32_t)(A.t & 0xffffffffu), (uint32_t)(A.t >> 32), 0u,
                               (uint32_t)(A.seed & 0xffffffffu), (uint32_t)(A.seed >> 32), u);
                 const bool explore = (float)(u[0] >> 8) * 0x1p-24f < A.epsilon;
@@ -380,19 +386,23 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     const float q = A.qcache[(size_t)a * N + e];
                     if (q > best) { best = q; a_greedy = a; }
                 }
-                const int a = explore ? a_rand : a_greedy;
+                a = explore ? a_rand : a_greedy;
                 SCG_STAMP(16);                                        // P: perm + qcache gathers, Philox, action
-                float sx = A.x[e], sy = A.y[e], svx = A.vx[e], svy = A.vy[e];
-                const int ep0 = A.ep_steps[e], o = A.option_id[e], osteps = A.opt_steps[e];   // early: latency hides under the physics
+                sx = A.x[e]; sy = A.y[e]; svx = A.vx[e]; svy = A.vy[e];
+                ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];   // early: latency hides under the physics
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
                 s_a[i] = (uint8_t)a;
-                if (helpers) lds_arrive(&s_misc[29], __popcll(__ballot(true)));      // state and action of these envs are out
-                // physics (SPEC §1.3)
-                bool goal;
-                SCG_STAMP(17);                                        // P: state gathers
-                const float rew = pinball_step_any(s_edges, A.cellmask, A.ms, sx, sy, svx, svy, a, goal);
-                SCG_STAMP(18);                                        // P: physics
+            }
+            if (helpers) lds_arrive(&s_misc[29], __popcll(__ballot(valid)));      // state and action of these envs are out
+            // physics (SPEC §1.3), the whole wave together
+            bool goal;
+            SCG_STAMP(17);                                        // P: state gathers
+            const float rew = pinball_step_wave_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal,
+                                                    s_pitems + wave * PITEMS, s_s + 4 * BLOCK_ENVS + wave * 64, BLOCK_ENVS,
+                                                    s_ia + wave * 64);
+            SCG_STAMP(18);                                        // P: physics
+            if (valid) {
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = ep0 + 1;
                 const bool timeout = !goal && eps1 >= A.max_ep;
@@ -479,7 +489,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
                 if (A.hist_next) atomicAdd(&A.hist_next[(e >> 8) * 8 + on], 1);   // next step's counting sort
-            } else if (MODE == MODE_TRANS) {
+            } else {
+                s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
+            }
+        } else if (valid) {
+            if (MODE == MODE_TRANS) {
                 s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
                 s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
                 s_s[4 * BLOCK_ENVS + i] = A.xn[e]; s_s[5 * BLOCK_ENVS + i] = A.yn[e];
@@ -496,9 +510,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         } else {
             s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
         }
-    } else if (helpers && wave >= BLOCK_ENVS / 32) {
-        const int ht = tid - BLOCK_ENVS / 32 * 64, hw = wave - BLOCK_ENVS / 32;       // helper thread / wave index (256 threads, 4 waves)
-        stage_w(A.W, ht, THREADS - BLOCK_ENVS / 32 * 64);
+    } else if (helpers && wave >= HELPER0) {
+        const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index (256 threads, 4 waves)
+        stage_w(A.W, ht, THREADS - HELPER0 * 64);
         lds_await(&s_misc[29], nb);                                                    // the P waves have published s and a
         if (ht < nb) {                                                                 // Z_d^1 of the entry states
             const float sv2 = fmaf(s_s[2 * BLOCK_ENVS + ht], 0.25f, 0.5f), sv3 = fmaf(s_s[3 * BLOCK_ENVS + ht], 0.25f, 0.5f);
@@ -529,8 +543,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
         }
         lds_arrive(&s_misc[28], 1);
-        lds_await(&s_misc[28], WAVES - BLOCK_ENVS / 32);                               // W_0, Z(s) and the list are complete
-        run_u1(hw, WAVES - BLOCK_ENVS / 32, rl, ro, 0);
+        lds_await(&s_misc[28], WAVES - HELPER0);                               // W_0, Z(s) and the list are complete
+        run_u1(hw, WAVES - HELPER0, rl, ro, 0);
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // From here on waves 0..3 run at priority 1 and waves 4..7 at 0: waves 0 and 1 build every pass's lists (the other
     // six wait for them at the next barrier) and the low waves hold the extra U2 tile. Measured against no priority:
     // +2.0 % env-steps/s; the same for waves 0..1 only; 0 % for waves 4..7, odd waves or one whole workgroup of the CU.
-    if (helpers) { if (wave < BLOCK_ENVS / 32) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    if (helpers) { if (wave < HELPER0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
