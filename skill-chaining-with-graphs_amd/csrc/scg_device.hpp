@@ -275,13 +275,30 @@ __device__ __forceinline__ float pinball_step_any(const float *edges, const uint
 constexpr int PCAP = 8;                        // candidate edges per env the pair form handles
 constexpr int PITEMS = 64 * PCAP + 64;         // pair slots per wave (a run never straddles a group of 64: up to 7 pad slots per group)
 
+// intercept() without its early exits (the same operations, every lane computes all of them): in the pair loop the exits were
+// exec-mask branches that cost more scalar instructions than the arithmetic they skipped
+__device__ __forceinline__ bool intercept_flat(const float4 ea, const float inv_len2, float R2, float x, float y, float vx, float vy) {
+    const float KAPPA2 = 0x1.0553bep-14f;
+    const float dx = x - ea.x, dy = y - ea.y;
+    float t = fmaf(dy, ea.w, dx * ea.z) * inv_len2;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float cx = fmaf(ea.z, t, ea.x), cy = fmaf(ea.w, t, ea.y);
+    const float bx = cx - x, by = cy - y;
+    const float d2 = fmaf(by, by, bx * bx);
+    const float dot = fmaf(by, vy, bx * vx);
+    const float vv = fmaf(vy, vy, vx * vx);
+    return !(d2 > R2) & ((dot >= 0.0f) | (dot * dot <= (KAPPA2 * d2) * vv));
+}
+
+// Part 1, by the wave that owns the envs (lane = env): impulse, candidate refinement, free flight for the envs without a
+// candidate, the per-lane loop for envs with more than PCAP, and the pair list of the others in `items` (runs of <= PCAP
+// consecutive slots, none straddling a group of 64). Returns the number of 64-slot groups to process (wave-uniform);
+// `par` = this lane's env is in the list (its state sits in xs, to be read back by pinball_wave_finish).
 template <int NW>
-__device__ __forceinline__ float pinball_step_wave(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
-                                                   bool valid, float &x, float &y, float &vx, float &vy, int a,
-                                                   bool &goal_out, uint32_t *items /* LDS [PITEMS], this wave's */,
-                                                   float *xs /* LDS [4][stride]: this wave's 64 slots start at xs */, int stride,
-                                                   uint8_t *gflag /* LDS [64], this wave's */) {
-    const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
+__device__ __forceinline__ int pinball_wave_prepare(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
+                                                    bool valid, float &x, float &y, float &vx, float &vy, int a,
+                                                    bool &goal, bool &par, uint32_t *items, float *xs, int stride) {
+    const float DV = 0x1.99999ap-3f, VMAX = 2.0f;
     const float4 *E4 = reinterpret_cast<const float4 *>(edges);
     const int lane = threadIdx.x & 63;
     if (a == 0) vx = vx + DV;
@@ -314,7 +331,7 @@ __device__ __forceinline__ float pinball_step_wave(const float *edges, const uin
     const float gr = ms.TR + (rr - 1.0f) * ms.R;
     const bool near_goal = valid && fmaf(gy0, gy0, gx0 * gx0) <= gr * gr;
     const float h = ms.hstep;
-    bool goal = false;
+    goal = false;
     // ---- envs without a candidate: free flight
     if (__ballot(valid && nc == 0)) {
         const bool wave_goal = __ballot(near_goal && nc == 0) != 0;
@@ -358,91 +375,100 @@ __device__ __forceinline__ float pinball_step_wave(const float *edges, const uin
             }
         }
     }
-    // ---- the others: one lane per (env, candidate edge)
-    const bool par = nc >= 1 && nc <= PCAP;
-    if (__ballot(par)) {
-        const int cnt = par ? nc : 0;
-        int p = cnt;                                           // exclusive prefix of cnt over the lanes
+    // ---- the others: one slot per (env, candidate edge)
+    par = nc >= 1 && nc <= PCAP;
+    if (!__ballot(par)) return 0;
+    const int cnt = par ? nc : 0;
+    int p = cnt;                                           // exclusive prefix of cnt over the lanes
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const int t = __shfl_up(p, m, 64);
-            if (lane >= m) p += t;
-        }
-        int total = __shfl(p, 63, 64);
-        p -= cnt;
-        for (int bnd = 64; bnd < total; bnd += 64) {           // no run may straddle a group of 64 pair slots: push it to the next group
-            const uint64_t cross = __ballot(cnt > 0 && p < bnd && p + cnt > bnd);
-            if (cross) {
-                const int src = (int)__builtin_ctzll(cross);
-                const int shift = bnd - __shfl(p, src, 64);
-                if (lane >= src) p += shift;
-                total += shift;
-            }
-        }
-        for (int q = lane; q < PITEMS; q += 64) items[q] = 0xffffffffu;      // pad slots stay empty
-        if (par) {
-            xs[lane] = x; xs[stride + lane] = y; xs[2 * stride + lane] = vx; xs[3 * stride + lane] = vy;
-            int c = 0;
-#pragma unroll
-            for (int g = 0; g < NW; ++g) {
-                uint64_t m = mask[g];
-                while (m) {
-                    const int j = g * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    items[p + c] = (unsigned)lane | ((unsigned)j << 8) | ((unsigned)c << 16) | ((unsigned)cnt << 20) | (near_goal ? 1u << 24 : 0u);
-                    ++c;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int r0 = 0; r0 < total; r0 += 64) {
-            const unsigned it = items[r0 + lane];
-            const bool act = it != 0xffffffffu;
-            const int src = act ? (int)(it & 63u) : 0, j = act ? (int)((it >> 8) & 255u) : 0;
-            const int c = (int)((it >> 16) & 15u), n = (int)((it >> 20) & 15u);
-            const uint64_t seg = act ? (((1ull << n) - 1ull) << (lane - c)) : 0ull;
-            const bool wave_goal = __ballot(act && ((it >> 24) & 1u)) != 0;
-            float px = xs[src], py = xs[stride + src], pvx = xs[2 * stride + src], pvy = xs[3 * stride + src];
-            const float4 ea = E4[2 * j];
-            const float4 eb = E4[2 * j + 1];                   // inv_len2, ux, uy, pad
-            bool pg = false;
-            for (int i = 0; i < 20; ++i) {
-                if (!pg) { px = fmaf(pvx, h, px); py = fmaf(pvy, h, py); }
-                const bool hit = act && !pg && intercept(ea, eb.x, ms.R2, px, py, pvx, pvy);
-                const uint64_t hits = __ballot(hit);
-                if (hits) {                                     // wave-uniform
-                    const uint64_t mine = hits & seg;
-                    const int nhit = __popcll(mine);
-                    const int fl = mine ? (int)__builtin_ctzll(mine) : lane;
-                    const float ux = __shfl(eb.y, fl, 64), uy = __shfl(eb.z, fl, 64);      // the lowest edge index among the hits
-                    if (nhit == 1) {
-                        const float pr = fmaf(pvy, uy, pvx * ux);
-                        const float tp = pr + pr;
-                        const float nvx = fmaf(tp, ux, -pvx), nvy = fmaf(tp, uy, -pvy);
-                        pvx = nvx; pvy = nvy;
-                        if (i == 19) { px = fmaf(pvx, h, px); py = fmaf(pvy, h, py); }
-                    } else if (nhit > 1) {
-                        pvx = -pvx; pvy = -pvy;
-                    }
-                }
-                if (wave_goal) {
-                    const float gx = px - ms.TX, gy = py - ms.TY;
-                    if (act && !pg && fmaf(gy, gy, gx * gx) < ms.TR2) pg = true;
-                }
-                if (!__ballot(act && !pg)) break;               // every env of this round is in the goal
-            }
-            if (act && c == 0) {
-                xs[src] = px; xs[stride + src] = py; xs[2 * stride + src] = pvx; xs[3 * stride + src] = pvy;
-                gflag[src] = pg ? 1 : 0;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (par) { x = xs[lane]; y = xs[stride + lane]; vx = xs[2 * stride + lane]; vy = xs[3 * stride + lane]; goal = gflag[lane] != 0; }
+    for (int m = 1; m < 64; m <<= 1) {
+        const int t = __shfl_up(p, m, 64);
+        if (lane >= m) p += t;
     }
+    int total = __shfl(p, 63, 64);
+    p -= cnt;
+    for (int bnd = 64; bnd < total; bnd += 64) {           // no run may straddle a group of 64 slots: push it to the next group
+        const uint64_t cross = __ballot(cnt > 0 && p < bnd && p + cnt > bnd);
+        if (cross) {
+            const int src = (int)__builtin_ctzll(cross);
+            const int shift = bnd - __shfl(p, src, 64);
+            if (lane >= src) p += shift;
+            total += shift;
+        }
+    }
+    const int groups = (total + 63) >> 6;
+    for (int q = lane; q < 64 * groups; q += 64) items[q] = 0xffffffffu;      // pad slots stay empty
+    if (par) {
+        xs[lane] = x; xs[stride + lane] = y; xs[2 * stride + lane] = vx; xs[3 * stride + lane] = vy;
+        int c = 0;
+#pragma unroll
+        for (int g = 0; g < NW; ++g) {
+            uint64_t m = mask[g];
+            while (m) {
+                const int j = g * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                items[p + c] = (unsigned)lane | ((unsigned)j << 8) | ((unsigned)c << 16) | ((unsigned)cnt << 20) | (near_goal ? 1u << 24 : 0u);
+                ++c;
+            }
+        }
+    }
+    return groups;
+}
+
+// Part 2, by ANY wave: the 20 sub-steps of one group of 64 pair slots. The envs' states are read from and written back to
+// xs (slots of the wave that owns them), their goal flags to gflag.
+__device__ __forceinline__ void pinball_wave_group(const float *edges, const MapScalars &ms, const uint32_t *items64,
+                                                   float *xs, int stride, uint8_t *gflag) {
+    const float4 *E4 = reinterpret_cast<const float4 *>(edges);
+    const int lane = threadIdx.x & 63;
+    const float h = ms.hstep;
+    const unsigned it = items64[lane];
+    const bool act = it != 0xffffffffu;
+    const int src = act ? (int)(it & 63u) : 0, j = act ? (int)((it >> 8) & 255u) : 0;
+    const int c = (int)((it >> 16) & 15u), n = (int)((it >> 20) & 15u);
+    const uint64_t seg = act ? (((1ull << n) - 1ull) << (lane - c)) : 0ull;
+    const bool wave_goal = __ballot(act && ((it >> 24) & 1u)) != 0;
+    float px = xs[src], py = xs[stride + src], pvx = xs[2 * stride + src], pvy = xs[3 * stride + src];
+    const float4 ea = E4[2 * j];
+    const float4 eb = E4[2 * j + 1];                       // inv_len2, ux, uy, pad
+    bool pg = false;
+    for (int i = 0; i < 20; ++i) {
+        if (!pg) { px = fmaf(pvx, h, px); py = fmaf(pvy, h, py); }
+        const bool hit = act & !pg & intercept_flat(ea, eb.x, ms.R2, px, py, pvx, pvy);
+        const uint64_t hits = __ballot(hit);
+        if (hits) {                                         // wave-uniform
+            const uint64_t mine = hits & seg;
+            const int nhit = __popcll(mine);
+            const int fl = mine ? (int)__builtin_ctzll(mine) : lane;
+            const float ux = __shfl(eb.y, fl, 64), uy = __shfl(eb.z, fl, 64);      // the lowest edge index among the hits
+            if (nhit == 1) {
+                const float pr = fmaf(pvy, uy, pvx * ux);
+                const float tp = pr + pr;
+                const float nvx = fmaf(tp, ux, -pvx), nvy = fmaf(tp, uy, -pvy);
+                pvx = nvx; pvy = nvy;
+                if (i == 19) { px = fmaf(pvx, h, px); py = fmaf(pvy, h, py); }
+            } else if (nhit > 1) {
+                pvx = -pvx; pvy = -pvy;
+            }
+        }
+        if (wave_goal) {
+            const float gx = px - ms.TX, gy = py - ms.TY;
+            if (act && !pg && fmaf(gy, gy, gx * gx) < ms.TR2) pg = true;
+            if (!__ballot(act && !pg)) break;               // every env of this group is in the goal
+        }
+    }
+    if (act && c == 0) {
+        xs[src] = px; xs[stride + src] = py; xs[2 * stride + src] = pvx; xs[3 * stride + src] = pvy;
+        gflag[src] = pg ? 1 : 0;
+    }
+}
+
+// Part 3, by the owning wave again: read the pair form's result back, then drag / clamp / reward (SPEC §1.3)
+__device__ __forceinline__ float pinball_wave_finish(bool par, float &x, float &y, float &vx, float &vy, int a, bool &goal,
+                                                     const float *xs, int stride, const uint8_t *gflag) {
+    const float DRAG = 0x1.fd70a4p-1f;
+    const int lane = threadIdx.x & 63;
+    if (par) { x = xs[lane]; y = xs[stride + lane]; vx = xs[2 * stride + lane]; vy = xs[3 * stride + lane]; goal = gflag[lane] != 0; }
     float reward;
     if (goal) {
         reward = 10000.0f;
@@ -451,16 +477,16 @@ __device__ __forceinline__ float pinball_step_wave(const float *edges, const uin
         x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f);
         reward = (a == 4) ? -1.0f : -5.0f;
     }
-    goal_out = goal;
     return reward;
 }
 
-__device__ __forceinline__ float pinball_step_wave_any(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
-                                                       bool valid, float &x, float &y, float &vx, float &vy, int a, bool &goal,
-                                                       uint32_t *items, float *xs, int stride, uint8_t *gflag) {
-    if (ms.n_edges <= 64) return pinball_step_wave<1>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, items, xs, stride, gflag);
-    if (ms.n_edges <= 128) return pinball_step_wave<2>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, items, xs, stride, gflag);
-    return pinball_step_wave<4>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, items, xs, stride, gflag);
+// dispatch on the number of mask words the map needs (wave-uniform)
+__device__ __forceinline__ int pinball_wave_prepare_any(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
+                                                        bool valid, float &x, float &y, float &vx, float &vy, int a, bool &goal,
+                                                        bool &par, uint32_t *items, float *xs, int stride) {
+    if (ms.n_edges <= 64) return pinball_wave_prepare<1>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, par, items, xs, stride);
+    if (ms.n_edges <= 128) return pinball_wave_prepare<2>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, par, items, xs, stride);
+    return pinball_wave_prepare<4>(edges, cellmask, ms, valid, x, y, vx, vy, a, goal, par, items, xs, stride);
 }
 
 // ------------------------------------------------------------------ SPEC §4.1

@@ -38,6 +38,8 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 constexpr int P_WAVES = BLOCK_ENVS / 64;      // phase P: one lane per env on full waves
 constexpr int HELPER0 = WAVES / 2;            // waves HELPER0.. work under phase P (learning steps)
+constexpr int P_POOL = HELPER0;               // waves 0..P_POOL-1 share the physics' (env, edge) pair groups
+static_assert(P_WAVES == 2, "the pair-group owner lookup below is written for two env waves");
 // LDS map of the step kernel (bytes). 8 wavefronts per workgroup, two workgroups per CU (80 KB each).
 constexpr int OFF_RC = 0;                                      // float r0,c0,ro,co (per env), rk,ck (per env, this pass) [128]
 constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia [128]
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 
     if (MODE == MODE_FUSED) {
         for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
-        if (tid == 0) { s_misc[31] = 1; s_misc[30] = 1; s_misc[29] = 0; s_misc[28] = 0; }  // [31]/[30] bit k: some env here has an item /
+        if (tid == 0) { s_misc[31] = 1; s_misc[30] = 1; s_misc[29] = 0; s_misc[28] = 0; s_misc[25] = 0; s_misc[24] = 0; }  // [31]/[30] bit k: some env here has an item /
                                                            // an UPDATE item for VF k; [29]/[28]: hand-off counters
         if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
         block_lds_sync();
@@ -398,10 +400,34 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             // physics (SPEC §1.3), the whole wave together
             bool goal;
             SCG_STAMP(17);                                        // P: state gathers
-            const float rew = pinball_step_wave_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal,
-                                                    s_pitems + wave * PITEMS, s_s + 4 * BLOCK_ENVS + wave * 64, BLOCK_ENVS,
-                                                    s_ia + wave * 64);
-            SCG_STAMP(18);                                        // P: physics
+            // the envs' own wave settles free flight and lists the (env, candidate edge) pairs of the others in groups of 64;
+            // the groups of BOTH env waves are then dealt to waves 0..P_POOL-1 (a wave whose 64 envs sit near walls would
+            // otherwise need two or three rounds of 20 sub-steps while its neighbours idle)
+            bool par;
+            float *xs_mine = s_s + 4 * BLOCK_ENVS + wave * 64;
+            const int groups = pinball_wave_prepare_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal, par,
+                                                        s_pitems + wave * PITEMS, xs_mine, BLOCK_ENVS);
+            if (lane == 0) s_misc[22 + wave] = groups;
+            lds_arrive(&s_misc[24], 1);
+            SCG_STAMP(18);                                        // P: physics, own part (refinement, free flight, pair lists)
+            {
+                lds_await(&s_misc[24], P_WAVES);
+                int gsum[P_WAVES + 1];
+                gsum[0] = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[22 + w2];
+                for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
+                    int owner = 0;
+#pragma unroll
+                    for (int w2 = 1; w2 < P_WAVES; ++w2) owner += q >= gsum[w2] ? 1 : 0;
+                    pinball_wave_group(s_edges, A.ms, s_pitems + owner * PITEMS + 64 * (q - (owner ? gsum[1] : 0)),
+                                       s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
+                }
+                lds_arrive(&s_misc[25], 1);
+                lds_await(&s_misc[25], P_POOL);
+            }
+            const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
+            SCG_STAMP(20);                                        // P: physics, the pooled pair groups + hand-offs
             if (valid) {
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = ep0 + 1;
@@ -510,6 +536,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         } else {
             s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
         }
+    } else if (MODE == MODE_FUSED && wave < P_POOL) {   // no envs of its own: takes its share of the physics' pair groups
+        lds_await(&s_misc[24], P_WAVES);
+        int gsum[P_WAVES + 1];
+        gsum[0] = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[22 + w2];
+        for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
+            int owner = 0;
+#pragma unroll
+            for (int w2 = 1; w2 < P_WAVES; ++w2) owner += q >= gsum[w2] ? 1 : 0;
+            pinball_wave_group(s_edges, A.ms, s_pitems + owner * PITEMS + 64 * (q - (owner ? gsum[1] : 0)),
+                               s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
+        }
+        lds_arrive(&s_misc[25], 1);
     } else if (helpers && wave >= HELPER0) {
         const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index (256 threads, 4 waves)
         stage_w(A.W, ht, THREADS - HELPER0 * 64);
