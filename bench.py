@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--diag-fresh-sort", action="store_true", help="diagnostic: stand-alone sort kernels every step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--event-every", type=int, default=0, help="HIP event pair round every n-th fused-kernel launch "
-                    "(0 = max(4, steps // 8): each pair costs a few us of queue bubble — 3 us per step when every other launch is sampled)")
+                    "(0 = max(8, steps // 8): each pair costs a few us of queue bubble — 3 us per step when every other launch is sampled)")
     ap.add_argument("--ramp", type=int, default=200, help="untimed clock-ramp step-batches before the warm-up "
                     "(a 20-step run otherwise times a cold GPU and the first step's stand-alone sort)")
     args = ap.parse_args()
@@ -245,7 +245,7 @@ def main():
     for _ in range(args.warmup):
         agent.step_batch(learn)
     barrier()
-    event_every = args.event_every if args.event_every > 0 else max(4, args.steps // 8)
+    event_every = args.event_every if args.event_every > 0 else max(8, args.steps // 8)
     lib.scg_profile_reset(ctx, event_every)       # HIP events round the fused kernel, on the launch stream
     if group is not None:
         agent.time_allreduce(event_every)         # ... and round the shared-weights all-reduce, as the step's stream sees it
