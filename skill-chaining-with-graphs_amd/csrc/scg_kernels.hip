@@ -427,7 +427,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 lds_await(&s_misc[25], P_POOL);
             }
             const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
-            SCG_STAMP(20);                                        // P: physics, the pooled pair groups + hand-offs
+            SCG_STAMP(2);                                         // P: physics, the pooled pair groups + hand-offs
             if (valid) {
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = ep0 + 1;

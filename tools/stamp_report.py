@@ -25,10 +25,10 @@ for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
 out = np.zeros((nblk, 32), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
-names = ["phase P (rest: trace, hist, barrier)", "root: phase Z + lists + W staging", "root: A operands -> registers", "root: E (eval)", "root: U1 (Q(s,a))",
+names = ["phase P (rest: trace, hist, barrier)", "root: phase Z + lists + W staging", "P: physics, pooled (env, edge) pair groups + hand-offs", "root: E (eval)", "root: U1 (Q(s,a))",
          "root: barrier at pass start", "root: U2 (accumulate)", "root: wait before U2", "opt: lists + W staging", "opt: A operands -> registers",
          "opt: E (eval)", "opt: U1 (Q(s,a))", "opt: barrier at pass start", "opt: U2 (accumulate)", "opt: wait before U2", "slab stores",
-         "P: perm, qcache, Philox, action", "P: state gathers", "P: physics", "P: bookkeeping, options, result line",
+         "P: perm, qcache, Philox, action", "P: state gathers", "P: physics, own part (refine, free flight, pair lists)", "P: bookkeeping, options, result line",
          "U2: MFMAs of a chunk + wait, but the last", "U2: build", "U2: wait for the other waves' build", "lists: flags + ballots", "lists: W staging", "lists: barrier behind the staging", "eval-only: wait", "eval-only: VALU evaluation", "(helper wave 4: kernel start -> its U1 done; not part of the total)"] + ["-"] * 3
 mean = out.astype(np.float64).mean(0) / args.steps
 tot = mean.sum() - mean[28]
