@@ -127,151 +127,18 @@ __device__ __forceinline__ float edge_d2(const float4 ea, const float inv_len2, 
 
 constexpr int CELL_G = 32;         // candidate-mask grid: 32 x 32 cells over the unit square
 
-// One env step. `edges` = LDS table [n_edges][8]; `cellmask` = global table [32*32][4] of 64-bit edge masks
-// (edges that can come within reach of any point of the cell at any legal speed — built on the host by
-// scg_set_map). NW = number of 64-bit mask words in use (n_edges <= 64 NW). Returns reward; goal by reference.
-template <int NW>
-__device__ __forceinline__ float pinball_step(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
-                                              float &x, float &y, float &vx, float &vy, int a, bool &goal_out) {
-    const float DV = 0x1.99999ap-3f, VMAX = 2.0f, DRAG = 0x1.fd70a4p-1f;
-    const float4 *E4 = reinterpret_cast<const float4 *>(edges);
-    // impulse + clip first: the speed |v| is now fixed for the whole step (mirror / reversal keep it)
-    if (a == 0) vx = vx + DV;
-    else if (a == 2) vx = vx - DV;
-    else if (a == 1) vy = vy + DV;
-    else if (a == 3) vy = vy - DV;
-    vx = fminf(fmaxf(vx, -VMAX), VMAX);
-    vy = fminf(fmaxf(vy, -VMAX), VMAX);
-    // Conservative candidate set (SPEC §1.3, last paragraph): the ball travels at most 21 |v| R/20 this step,
-    // so only edges within R (1 + 1.05 |v|) of the start position can be intercepted. The bound need not be
-    // exact, only safe: 1.10 instead of 1.05 and +2 % on the radius swallow the approximate sqrt and rounding.
-    // The cell mask narrows 47..256 edges to the handful near the ball's cell; those are refined exactly.
-    const float spd = __builtin_sqrtf(fmaf(vy, vy, vx * vx));
-    const float rr = fmaf(1.10f, spd, 1.02f);
-    const float reach2 = ms.R2 * rr * rr;
-    const int cxi = min(max((int)(x * (float)CELL_G), 0), CELL_G - 1);
-    const int cyi = min(max((int)(y * (float)CELL_G), 0), CELL_G - 1);
-    const uint64_t *cm = cellmask + (size_t)(cyi * CELL_G + cxi) * 4;
-    // Refine the cell mask exactly and keep the first KC survivors IN REGISTERS (edge index ascending, so
-    // "first intercepted edge" keeps its meaning); the 20 sub-steps then run without LDS round trips.
-    // Lanes with more than KC candidates (corners of dense maps) keep the rest in `over` and fall back
-    // to the LDS loop for those.
-    constexpr int KC = 3;
-    float cx0[KC], cy0[KC], cex[KC], cey[KC], cinv[KC];
-    int cidx[KC];
-    int nc = 0;
-    uint64_t over[NW];
-#pragma unroll
-    for (int q = 0; q < KC; ++q) { cx0[q] = 0.0f; cy0[q] = 0.0f; cex[q] = 0.0f; cey[q] = 0.0f; cinv[q] = 0.0f; cidx[q] = -1; }
-    bool any_over = false;
-#pragma unroll
-    for (int g = 0; g < NW; ++g) {
-        uint64_t m = cm[g], out = 0;
-        while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            const int j = g * 64 + b;
-            const float4 ea = E4[2 * j];
-            const float inv = edges[8 * j + 4];
-            if (edge_d2(ea, inv, x, y) <= reach2) {
-                if (nc < KC) {
-#pragma unroll
-                    for (int q = 0; q < KC; ++q)
-                        if (q == nc) { cx0[q] = ea.x; cy0[q] = ea.y; cex[q] = ea.z; cey[q] = ea.w; cinv[q] = inv; cidx[q] = j; }
-                    ++nc;
-                } else {
-                    out |= (1ull << b);
-                }
-            }
-        }
-        over[g] = out;
-        any_over = any_over || (out != 0);
-    }
-    const bool any = nc > 0;
-    // the goal disc can only be entered if it starts within reach as well
-    const float gx0 = x - ms.TX, gy0 = y - ms.TY;
-    const float gr = ms.TR + (rr - 1.0f) * ms.R;                       // TR + 1.10 |v| R + 2 % R
-    const bool near_goal = fmaf(gy0, gy0, gx0 * gx0) <= gr * gr;
-    bool goal = false;
-    const float h = ms.hstep;
-    const bool wave_any = __ballot(any) != 0;             // wave-uniform: nobody near an edge -> free flight
-    const bool wave_over = __ballot(any_over) != 0;
-    const bool wave_goal = __ballot(near_goal) != 0;
-    bool wslot[KC];
-#pragma unroll
-    for (int q = 0; q < KC; ++q) wslot[q] = __ballot(nc > q) != 0;
-    for (int i = 0; i < 20; ++i) {
-        x = fmaf(vx, h, x); y = fmaf(vy, h, y);
-        int nhit = 0, first = -1;
-        if (wave_any) {
-#pragma unroll
-            for (int q = 0; q < KC; ++q) {
-                if (wslot[q]) {
-                    const bool hit = (nc > q) && intercept(make_float4(cx0[q], cy0[q], cex[q], cey[q]), cinv[q], ms.R2, x, y, vx, vy);
-                    if (hit) { if (nhit == 0) first = cidx[q]; ++nhit; }
-                }
-            }
-            if (wave_over) {
-#pragma unroll
-                for (int g = 0; g < NW; ++g) {
-                    uint64_t m = over[g];
-                    while (m) {
-                        const int j = g * 64 + __builtin_ctzll(m);
-                        m &= m - 1;
-                        if (intercept(E4[2 * j], edges[8 * j + 4], ms.R2, x, y, vx, vy)) {
-                            if (nhit == 0) first = j;
-                            ++nhit;
-                        }
-                    }
-                }
-            }
-            if (__ballot(nhit > 0)) {
-                if (nhit == 1) {
-                    const float ux = edges[8 * first + 5], uy = edges[8 * first + 6];
-                    const float pr = fmaf(vy, uy, vx * ux);
-                    const float tp = pr + pr;
-                    const float nvx = fmaf(tp, ux, -vx), nvy = fmaf(tp, uy, -vy);
-                    vx = nvx; vy = nvy;
-                    if (i == 19) { x = fmaf(vx, h, x); y = fmaf(vy, h, y); }
-                } else if (nhit > 1) {
-                    vx = -vx; vy = -vy;
-                }
-            }
-        }
-        if (wave_goal) {
-            const float gx = x - ms.TX, gy = y - ms.TY;
-            if (fmaf(gy, gy, gx * gx) < ms.TR2) { goal = true; break; }
-        }
-    }
-    float reward;
-    if (goal) {
-        reward = 10000.0f;
-    } else {
-        vx = vx * DRAG; vy = vy * DRAG;
-        x = fminf(fmaxf(x, 0.0f), 1.0f); y = fminf(fmaxf(y, 0.0f), 1.0f);
-        reward = (a == 4) ? -1.0f : -5.0f;
-    }
-    goal_out = goal;
-    return reward;
-}
-
-// dispatch on the number of mask words the map needs (wave-uniform)
-__device__ __forceinline__ float pinball_step_any(const float *edges, const uint64_t *cellmask, const MapScalars &ms,
-                                                  float &x, float &y, float &vx, float &vy, int a, bool &goal) {
-    if (ms.n_edges <= 64) return pinball_step<1>(edges, cellmask, ms, x, y, vx, vy, a, goal);
-    if (ms.n_edges <= 128) return pinball_step<2>(edges, cellmask, ms, x, y, vx, vy, a, goal);
-    return pinball_step<4>(edges, cellmask, ms, x, y, vx, vy, a, goal);
-}
-
+// `edges` = LDS table [n_edges][8]; `cellmask` = global table [32*32][4] of 64-bit edge masks (edges that can come within reach
+// of any point of the cell at any legal speed — built on the host by scg_set_map). NW = number of 64-bit mask words in use
+// (n_edges <= 64 NW).
 // ------------------------------------------------------------------ SPEC §1.3, a whole wavefront of envs at once
-// The per-lane form above walks every candidate edge of its env one after another, 20 times, and a wave is as slow as its
-// env with the most candidates: on the bench workload half the envs have no edge within reach at all, a third have two
+// A per-lane form (rounds 1-2: one env per lane, three candidate edges in registers + an overflow loop) walks every candidate
+// edge of its env one after another, 20 times, and a wave is as slow as its env with the most candidates: on the bench workload half the envs have no edge within reach at all, a third have two
 // or more, and every 32-lane wave held some of each (3 register slots + the overflow loop = ~110 vector instructions per
 // sub-step for everybody). Here the wave first settles the envs without candidates (free flight: 2 fmas + the goal test per
 // sub-step), then deals the (env, candidate edge) PAIRS of the others to its lanes — one intercept per lane and sub-step —
 // and combines the hits of an env's lanes (a run of <= PCAP consecutive lanes) with one ballot: count = popcount, first hit
 // = lowest set bit, i.e. the lowest edge index, as SPEC §1.3 asks. Same candidate set, same tests, same order of
-// operations per env: bit-identical to pinball_step(). Envs with more than PCAP candidates take the per-lane loop.
+// operations per env as that form. Envs with more than PCAP candidates take a per-lane loop over their candidate mask.
 constexpr int PCAP = 8;                        // candidate edges per env the pair form handles
 constexpr int PITEMS = 64 * PCAP + 64;         // pair slots per wave (a run never straddles a group of 64: up to 7 pad slots per group)
 

@@ -1523,16 +1523,28 @@ __global__ __launch_bounds__(COL_ROW) void collect_scatter_kernel(int n, const u
 __global__ __launch_bounds__(256) void pinball_kernel(int n, float *x, float *y, float *vx, float *vy,
                                                       const uint8_t *action, float *reward, uint8_t *goal,
                                                       const float *edges, const uint64_t *cellmask, MapScalars ms) {
+    // the fused step's physics, wave by wave (pinball_wave_*: free flight in place, (env, edge) pairs on the wave's own lanes)
     __shared__ __attribute__((aligned(16))) float s_edges[MAX_EDGES * 8];
+    __shared__ uint32_t s_items[4][PITEMS];
+    __shared__ float s_xs[4][4 * 64];
+    __shared__ uint8_t s_g[4][64];
     for (int i = threadIdx.x; i < ms.n_edges * 8; i += 256) s_edges[i] = edges[i];
     __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    float sx = x[e], sy = y[e], svx = vx[e], svy = vy[e];
-    bool g;
-    const float r = pinball_step_any(s_edges, cellmask, ms, sx, sy, svx, svy, action[e], g);
-    x[e] = sx; y[e] = sy; vx[e] = svx; vy[e] = svy;
-    reward[e] = r; goal[e] = g ? 1 : 0;
+    const int e = blockIdx.x * 256 + threadIdx.x, wv = threadIdx.x >> 6;
+    const bool valid = e < n;
+    float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
+    int a = NACT - 1;
+    if (valid) { sx = x[e]; sy = y[e]; svx = vx[e]; svy = vy[e]; a = action[e]; }
+    bool g, par;
+    const int groups = pinball_wave_prepare_any(s_edges, cellmask, ms, valid, sx, sy, svx, svy, a, g, par, s_items[wv], s_xs[wv], 64);
+    wave_lds_sync();
+    for (int q = 0; q < groups; ++q) pinball_wave_group(s_edges, ms, s_items[wv] + 64 * q, s_xs[wv], 64, s_g[wv]);
+    wave_lds_sync();
+    const float r = pinball_wave_finish(par, sx, sy, svx, svy, a, g, s_xs[wv], 64, s_g[wv]);
+    if (valid) {
+        x[e] = sx; y[e] = sy; vx[e] = svx; vy[e] = svy;
+        reward[e] = r; goal[e] = g ? 1 : 0;
+    }
 }
 
 // one wavefront per env: materialises phi[n][1296] (the fused path never does this)

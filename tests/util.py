@@ -67,3 +67,21 @@ def dense_map(n_side=6, size=0.035):
             cx, cy = 0.16 + 0.136 * i, 0.16 + 0.136 * j
             lines.append(f"polygon {cx - size} {cy - size} {cx + size} {cy - size} {cx + size} {cy + size} {cx - size} {cy + size}")
     return scg.parse_map("\n".join(lines), "dense_synthetic")
+
+
+def hub_map(n_spokes=12, r_in=0.035, r_out=0.30, half_width=0.006):
+    """Thin spokes radiating from the centre (16 + 4 n_spokes edges): a ball near the hub has a dozen or more edges
+    within reach at once — more than the (env, edge) pair form of the HIP physics takes per env (> 8: its per-lane
+    loop) — and the balls around it have 3..8 (pair runs of every length, several groups of 64 pairs per wave)."""
+    lines = ["ball 0.02", "target 0.9 0.1 0.04", "start 0.5 0.5 0.1 0.9 0.5 0.5",
+             "polygon 0.0 0.0 0.0 0.01 1.0 0.01 1.0 0.0", "polygon 0.0 0.0 0.01 0.0 0.01 1.0 0.0 1.0",
+             "polygon 0.0 1.0 0.0 0.99 1.0 0.99 1.0 1.0", "polygon 1.0 1.0 0.99 1.0 0.99 0.0 1.0 0.0"]
+    for k in range(n_spokes):
+        t = 2 * np.pi * (k + 0.5) / n_spokes
+        c, s_ = np.cos(t), np.sin(t)
+        pts = [(0.5 + r_in * c - half_width * s_, 0.5 + r_in * s_ + half_width * c),
+               (0.5 + r_out * c - half_width * s_, 0.5 + r_out * s_ + half_width * c),
+               (0.5 + r_out * c + half_width * s_, 0.5 + r_out * s_ - half_width * c),
+               (0.5 + r_in * c + half_width * s_, 0.5 + r_in * s_ - half_width * c)]
+        lines.append("polygon " + " ".join(f"{px:.6f} {py:.6f}" for px, py in pts))
+    return scg.parse_map("\n".join(lines), f"hub_{n_spokes}")
