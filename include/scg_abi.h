@@ -161,6 +161,12 @@ int scg_harvest(scg_ctx *ctx, int32_t n_sel, const int32_t *sel_env, const float
  * fit is dropped. The trace buffers of scg_set_trace_buffers are read. */
 int scg_collect_examples(scg_ctx *ctx, uint32_t event_bits, uint8_t *prev_in, int32_t l_pos, int32_t l_neg,
                          float *ex_xy, uint8_t *ex_label, int32_t *count, int32_t cap, void *stream);
+/* Optional: announce the trigger the NEXT scg_collect_examples will be called with (same event_bits, prev_in, l_pos + l_neg and
+ * count). Every following scg_step then leaves the per-row example totals behind while it commits its results (the rows are
+ * the same), and a matching scg_collect_examples right after it needs one launch instead of two. Results are identical either
+ * way; a call that does not match the announcement, or comes without a step in between, takes the two-launch path.
+ * event_bits = 0 withdraws the announcement. */
+int scg_arm_collect(scg_ctx *ctx, uint32_t event_bits, const uint8_t *prev_in, int32_t l_pos, int32_t l_neg, const int32_t *count);
 
 /* Gestation (SPEC §4.4; Konidaris & Barto 2009: a new option learns off-policy before it may run). Bit k of gest_mask:
  * option k's classifier is in use (initiation / target tests, event bits) but the option is never selected; every env

@@ -66,6 +66,7 @@ _SIGS = {
     "scg_set_trace_buffers": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "scg_harvest": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "scg_collect_examples": (C.c_int, [_P, C.c_uint32, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P]),
+    "scg_arm_collect": (C.c_int, [_P, C.c_uint32, _P, C.c_int32, C.c_int32, _P]),
     "scg_set_gestation": (C.c_int, [_P, C.c_uint32, _P]),
     "scg_profile_reset": (C.c_int, [_P, C.c_int32]),
     "scg_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -92,6 +92,7 @@ class SkillChainingAgent:
         (SPEC §4.4, Konidaris & Barto 2009): its classifier is in use, it is never selected, every transition from inside
         its initiation set updates its value function off-policy, and poll_gestation() enables it once G such
         transitions have reached its target. Returns the training accuracy."""
+        self.ctx.disarm_collect()            # the collection for this option is over
         xy, lab = self.examples(k)
         if self.group is not None:           # fit on the examples of ALL ranks (rank order): identical classifiers everywhere
             xy, lab = _dist.allgather_rows(xy.contiguous(), self.group), _dist.allgather_rows(lab.contiguous(), self.group)

@@ -178,7 +178,7 @@ class ScgContext:
         return xy, lab
 
     def collect_examples(self, event_bits: int, prev_in: Optional[torch.Tensor], l_pos: int, l_neg: int,
-                         ex_xy: torch.Tensor, ex_label: torch.Tensor, count: torch.Tensor) -> None:
+                         ex_xy: torch.Tensor, ex_label: torch.Tensor, count: torch.Tensor, rearm: bool = True) -> None:
         """SPEC §7 device-side trigger: envs whose events byte has one of `event_bits` set (with prev_in: on the step the
         bit goes up) append their most recent ring states to ex_xy[cap, 2] / ex_label[cap] behind the count[0] examples
         already there (device int32[1], in/out). One launch, nothing comes back to the host."""
@@ -193,6 +193,11 @@ class ScgContext:
             raise ScgError("collect_examples: bad argument")
         self._call("scg_collect_examples", C.c_uint32(event_bits), _ptr(prev_in), l_pos, l_neg, _ptr(ex_xy), _ptr(ex_label),
                    _ptr(count), cap, self._stream())
+        if rearm:            # the same trigger will come again after the next step: let that step leave the row totals behind
+            self._call("scg_arm_collect", C.c_uint32(event_bits), _ptr(prev_in), l_pos, l_neg, _ptr(count))
+
+    def disarm_collect(self) -> None:
+        self._call("scg_arm_collect", C.c_uint32(0), None, 0, 0, None)
 
     def set_gestation(self, gest_mask: int) -> torch.Tensor:
         """SPEC §4.4: options in gestation (known, never selected, learning off-policy). Returns the device int32[n_vf]

@@ -1011,6 +1011,12 @@ struct ReduceArgs {
     uint8_t *action, *done;
     float *qcache;                 // [5][n], null = the step ran no TD pass (diagnostic): leave it alone
     int32_t sort;
+    // an announced example trigger (scg_arm_collect; c_rows null = none): the commit rows leave what collect_count_kernel would
+    const uint8_t *c_events, *c_prev;
+    const int32_t *c_evlen, *c_count;
+    int32_t *c_rows;
+    uint32_t c_bits;
+    int32_t c_L, c_ring_len;
 };
 
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
@@ -1037,6 +1043,8 @@ __device__ __forceinline__ int sort_key(const int32_t *option_id, int e, int n, 
 // floor(r / d) for r < 2^24, d <= 2^30, with m = ceil(2^32 / d) (m wraps to 0 for d = 1)
 __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xFFFFFFFFu / d + 1u; }
 __device__ __forceinline__ int div_by(int r, int d, uint32_t m) { return d == 1 ? r : (int)__umulhi((uint32_t)r, m); }
+__device__ __forceinline__ int collect_v(int e, int n, const uint8_t *events, const uint8_t *prev_in, uint32_t bits,
+                                         const int32_t *ev_len, int ring_len, int L, bool &in_out);
 struct OrderLayout {
     int chunked, c, g, U, Ftot;
     uint32_t mc, mg;               // ceil(2^32 / c), ceil(2^32 / g): exact division of ranks (< 2^24) by mul-high
@@ -1185,9 +1193,20 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
             }
         }
     }
-    if (!R.sort) return;                                    // workgroup-uniform
+    if (R.c_rows && act) {                                  // the announced trigger's examples of this wave's envs (SPEC §7)
+        bool in;
+        int v = collect_v(e, R.n, R.c_events, R.c_prev, R.c_bits, R.c_evlen, R.c_ring_len, R.c_L, in);
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) s_x[wv][21] = v;
+    }
+    if (!R.sort && !R.c_rows) return;                       // workgroup-uniform
     __syncthreads();
-    if (!act) return;
+    if (R.c_rows && wv == 0 && lane == 0 && row < R.nrow) {
+        R.c_rows[row] = s_x[0][21] + s_x[1][21] + s_x[2][21] + s_x[3][21];
+        if (row == 0) R.c_rows[R.nrow] = *R.c_count;        // the buffer's fill level
+    }
+    if (!R.sort || !act) return;
     int off[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -1423,7 +1442,8 @@ __global__ __launch_bounds__(256) void harvest_kernel(int n_sel, const int32_t *
     out_label[t] = ok ? (j < l_pos ? 1 : 0) : 255;
 }
 
-// SPEC §7 device-side trigger + harvest (no host round trip per step), two small launches over rows of COL_ROW envs.
+// SPEC §7 device-side trigger + harvest (no host round trip per step), two small launches over rows of COL_ROW envs — or one,
+// when the trigger was announced with scg_arm_collect: the commit rows of the step's own last launch then leave the row totals.
 // An env is selected when (events & bits) != 0 — with `prev_in` given, only on the step it ENTERS that state (prev_in is
 // updated). A selected env contributes its v = min(L, ev_len, ring_len) most recent ring states (age j < l_pos: label 1,
 // else 0), appended behind the *count examples the buffer already holds, in env order, ages ascending; what does not fit
@@ -1434,7 +1454,7 @@ __global__ __launch_bounds__(256) void harvest_kernel(int n_sel, const int32_t *
 //                           lanes of its wave together (lane j = age j), not one after another by the env's own lane
 // Deterministic: every position is a prefix sum of integers in env order. (Round 2 walked the envs with ONE workgroup,
 // 1024 at a time behind three barriers each: 64 dependent memory round trips per step-batch at the bench size.)
-constexpr int COL_ROW = 1024;
+constexpr int COL_ROW = 256;                   // = the env rows of the commit workgroups, which can stand in for collect_count_kernel
 
 __device__ __forceinline__ int collect_v(int e, int n, const uint8_t *events, const uint8_t *prev_in, uint32_t bits,
                                          const int32_t *ev_len, int ring_len, int L, bool &in_out) {
@@ -1705,6 +1725,11 @@ struct scg_ctx {
     uint64_t *d_cellmask;
     int32_t *d_perm, *d_hist;      // SPEC §5 env order of the current step (d_hist: scratch of the stand-alone sort)
     int32_t *d_collect_rows;       // scg_collect_examples: per-row totals [rows of COL_ROW envs] + the buffer's fill level
+    uint32_t arm_bits;             // scg_arm_collect: the announced trigger (0 = none) ...
+    const uint8_t *arm_prev;
+    const int32_t *arm_count;
+    int32_t arm_L;
+    bool arm_rows_ready;           // ... and whether the last scg_step left its row totals in d_collect_rows
     unsigned long long *d_fit_part;   // fit_kernel: tagged workgroup partials [FIT_BATCH][2][FIT_G][8]
     uint32_t *h_async;             // pinned, device-visible status word: kernels that give up OR their reason into it
     uint32_t *d_async;             // ... its device address
@@ -2027,6 +2052,10 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
         R.option_id_out = st->option_id; R.opt_steps = st->opt_steps; R.ep_steps = st->ep_steps;
         R.action = st->action; R.done = st->done;
         R.qcache = st->k_hi >= 0 ? st->qcache : nullptr;
+        if (c->arm_bits && c->events && c->ring_x) {
+            R.c_events = c->events; R.c_prev = c->arm_prev; R.c_evlen = c->ev_len; R.c_count = c->arm_count;
+            R.c_rows = c->d_collect_rows; R.c_bits = c->arm_bits; R.c_L = c->arm_L; R.c_ring_len = c->ring_len;
+        }
     }
     if (!reduce) {                                       // acting-only step: the commit alone
         hipLaunchKernelGGL(commit_kernel, dim3(nrow), dim3(256), 0, s, R);
@@ -2095,6 +2124,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     SCG_HIP(c, hipGetLastError());
     if (ev1) SCG_HIP(c, hipEventRecord(ev1, s));
     // results reach the caller's arrays through the commit workgroups of the reduce launch (or a commit launch)
+    c->arm_rows_ready = c->arm_bits && c->events && c->ring_x;      // ... which also leave an announced trigger's row totals
     if (!(flags & SCG_STEP_LEARN)) return launch_reduce(c, W, 0u, c->nblk, s, &A, false, false);
     if (!fold) return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, c->nblk, s, &A, false);
     c->hist_dirty = true;                          // until the reduce launch has consumed and re-armed the counts
@@ -2155,6 +2185,10 @@ int scg_collect_examples(scg_ctx *c, uint32_t event_bits, uint8_t *prev_in, int3
     SCG_ON_DEVICE(c, "scg_collect_examples");
     const int nrows = (c->cfg.n_envs + COL_ROW - 1) / COL_ROW;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool have_rows = c->arm_rows_ready && c->arm_bits == event_bits && c->arm_prev == prev_in && c->arm_count == count &&
+                           c->arm_L == l_pos + l_neg;
+    c->arm_rows_ready = false;                               // prev_in changes below: the totals are used up
+    if (!have_rows)
     hipLaunchKernelGGL(collect_count_kernel, dim3(nrows), dim3(COL_ROW), 0, s, c->cfg.n_envs, c->events, prev_in, event_bits,
                        c->ev_len, c->ring_len, l_pos + l_neg, c->d_collect_rows, nrows, count);
     hipLaunchKernelGGL(collect_scatter_kernel, dim3(nrows), dim3(COL_ROW), 0, s, c->cfg.n_envs, c->events, prev_in, event_bits,
@@ -2164,9 +2198,20 @@ int scg_collect_examples(scg_ctx *c, uint32_t event_bits, uint8_t *prev_in, int3
     return SCG_OK;
 }
 
+int scg_arm_collect(scg_ctx *c, uint32_t event_bits, const uint8_t *prev_in, int32_t l_pos, int32_t l_neg, const int32_t *count) {
+    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_arm_collect: null ctx");
+    c->arm_rows_ready = false;
+    if (event_bits == 0) { c->arm_bits = 0; return SCG_OK; }
+    if (l_pos < 0 || l_neg < 0 || l_pos + l_neg < 1 || !count) return fail(c, SCG_ERR_INVALID, "scg_arm_collect: bad argument");
+    if (!c->ring_x || !c->events) return fail(c, SCG_ERR_STATE, "scg_arm_collect: trace buffers are not attached");
+    c->arm_bits = event_bits; c->arm_prev = prev_in; c->arm_count = count; c->arm_L = l_pos + l_neg;
+    return SCG_OK;
+}
+
 int scg_set_trace_buffers(scg_ctx *c, float *ring_x, float *ring_y, int32_t ring_len, uint8_t *events,
                           int32_t *ev_len) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_trace_buffers: null ctx");
+    c->arm_bits = 0; c->arm_rows_ready = false;             // an announced trigger refers to the old buffers
     if ((ring_x == nullptr) != (ring_y == nullptr)) return fail(c, SCG_ERR_INVALID, "scg_set_trace_buffers: ring_x and ring_y go together");
     if (ring_x && (ring_len < 1 || (ring_len & (ring_len - 1)))) return fail(c, SCG_ERR_INVALID, "scg_set_trace_buffers: ring_len must be a power of two");
     if ((events == nullptr) != (ev_len == nullptr)) return fail(c, SCG_ERR_INVALID, "scg_set_trace_buffers: events and ev_len go together");

@@ -310,3 +310,38 @@ def test_checkpoint_resume_continues_bit_identically(tmp_path):
         assert torch.equal(ta, tb)
     assert a.examples_held(2) == b.examples_held(2) > 0
     assert torch.equal(a.examples(2)[0], b.examples(2)[0]) and torch.equal(a.examples(2)[1], b.examples(2)[1])
+
+
+@pytest.mark.gpu
+def test_announced_trigger_gives_the_same_examples_in_one_launch():
+    """scg_arm_collect: the step's commit rows leave the per-row example totals, the following collect skips its count
+    launch. Two agents on the same seed, one announcing (the default of ctx.collect_examples) and one not, must hold
+    identical example buffers, counts and prev_in after every step-batch — including a step whose collect is skipped
+    (stale announcement: the next collect must fall back to counting itself)."""
+    import torch
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    from util import HP
+    ags = []
+    for _ in range(2):
+        ag = SkillChainingAgent("pinball_simple", 3000, 2, seed=9, **dict(HP, max_episode_steps=60))
+        ag.clf.copy_(torch.as_tensor(chain_classifiers(ag.map, 2), device="cuda:0"))
+        ag.enable_option(1)
+        ag.init_weights(std=1e-2)
+        ag.domain.reset_random(seed=4, v_max=1.5)
+        ag.enable_tracing(ring_len=32, max_examples=1 << 16)
+        ags.append(ag)
+    a, b = ags
+    for t in range(40):
+        for ag in ags:
+            ag.step_batch()
+        if t % 7 == 3:
+            continue                                      # no collect after this step: a's announcement goes stale
+        xy, lab, cnt, prev = a._ex_buffers(2)
+        a.ctx.collect_examples(1 << 1, prev, 8, 8, xy.view(-1), lab, cnt, rearm=True)
+        xy, lab, cnt, prev = b._ex_buffers(2)
+        b.ctx.collect_examples(1 << 1, prev, 8, 8, xy.view(-1), lab, cnt, rearm=False)
+    torch.cuda.synchronize()
+    na, nb = a.examples_held(2), b.examples_held(2)
+    assert na == nb and na > 100
+    for ta, tb in zip(a._ex_buffers(2), b._ex_buffers(2)):
+        assert torch.equal(ta, tb)
