@@ -99,6 +99,14 @@ enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 template <typename T>
 __device__ __forceinline__ void gstore(T *p, T v) { *p = v; }
 
+// 16-byte WRITE-THROUGH store (sc1) for data that only the NEXT launch reads — the slabs: 27 MB per step-batch. A plain store
+// leaves the lines dirty in the XCD's L2 and the kernel boundary then waits for their write-back (MI355X_MICROARCH.md, "boundary":
+// + B / 6 TB/s); written through, they are in the memory-side cache by then, where the reduce launch (other XCDs) reads them
+// anyway: +1.1 % env-steps/s. (`nt` stores, round 2, bypassed that cache too and cost the reduce launch 5.7 us.)
+__device__ __forceinline__ void store_wt(float *p, f4v v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+
 struct StepArgs {
     // env state (FUSED: in/out; TRANS/QVAL: in)
     float *x, *y, *vx, *vy;
@@ -878,7 +886,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     if (s == 0 || wave_u == a) {
                         const int mi = (q * 11) >> 5, ni = q - 3 * mi;         // wave-uniform
                         const bool okl = (mi < 2 || n16 < 4) && (ni < 2 || g == 0);
-                        if (okl) *reinterpret_cast<f4v *>(slab_lane + a * NF + (16 * mi) * 36 + 16 * ni) = accU[a][s];
+                        if (okl) store_wt(slab_lane + a * NF + (16 * mi) * 36 + 16 * ni, accU[a][s]);
                     }
                 }
             }
