@@ -300,7 +300,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                         "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 44 % busy), not HBM-bound (SURVEY.md \u00a78d, "
+                         "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 46 % busy), not HBM-bound (SURVEY.md \u00a78d, "
                                  "DESIGN.md): see `mfma` for the binding roofline"},
         }
         # the binding (matrix-pipe) roofline: algorithmic flops of the TD items this rank processed per step
