@@ -335,23 +335,24 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // workgroup instead of a 27 KB gather per wave: every workgroup of the chip wants the same 26 KB at the same moment,
     // and the L2 channels holding them were the bottleneck.
     auto stage_w = [&](const float *Wk, int ht, int nth) {
-        const float4 *Wk4 = reinterpret_cast<const float4 *>(Wk);
-        for (int f4 = ht; f4 < NACT * NF / 4; f4 += nth) {
-            const float4 w = Wk4[f4];
-            const int row = f4 / 9, c0 = 4 * (f4 - 9 * row);
-            const int t = row >> 4, nn = row & 15;
-            const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = c0 + e, gg = (c * 57) >> 9, kb = c - 9 * gg;      // c / 9, c % 9 for c < 36
-                const int ln = gg * 16 + nn;
-                s_W[kb < 8 ? ((t * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + t * 64 + ln] = wv[e];
+        // one thread per DESTINATION float4 (row tile t, k-block half hk, lane (nn, gg)): its four values W[16 t + nn][9 gg + 4 hk ..
+        // + 3] are consecutive in the source row — a 16-byte load at a 4-byte-aligned address — and go out as one linear
+        // ds_write_b128. (Round 2 walked the SOURCE float4s and scattered each into four places: ~45 instructions of index
+        // arithmetic per float4 and 2.5-way bank conflicts on the stores.)
+        struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+        f4v *dst4 = reinterpret_cast<f4v *>(s_W);
+        for (int d = ht; d < 12 * 2 * 64; d += nth) {
+            const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
+            f4v v = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            if (row < NACT * 36) {
+                const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
+                v = (f4v){w.x, w.y, w.z, w.w};
             }
+            dst4[d] = v;
         }
-        for (int z = ht; z < 9 * 4 * 12; z += nth) {                             // tile 11, rows 180..191
-            const int kb = z / 48, r = z - 48 * kb, gg = r / 12, nn = 4 + (r - 12 * gg);
-            const int ln = gg * 16 + nn;
-            s_W[kb < 8 ? ((11 * 2 + (kb >> 2)) * 64 + ln) * 4 + (kb & 3) : W_TAIL + 11 * 64 + ln] = 0.0f;
+        for (int z = ht; z < 12 * 64; z += nth) {                                 // k-block 8 of every tile
+            const int ln = z & 63, row = 16 * (z >> 6) + (ln & 15);
+            s_W[W_TAIL + z] = row < NACT * 36 ? Wk[row * 36 + 9 * (ln >> 4) + 8] : 0.0f;
         }
     };
     // counters in LDS for hand-offs between SUBSETS of the workgroup's waves (s_barrier takes all eight): a producer
