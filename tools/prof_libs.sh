@@ -1,4 +1,4 @@
-# usage: bash tools/_prof.sh lib1 lib2 ... : rocprofv3 kernel stats of the bench per library
+# usage (on the GPU box, from the repo root): bash tools/prof_libs.sh NAME1 NAME2 ... — rocprofv3 kernel stats of the bench for csrc/libscg_hip_NAME.so builds (A/B of kernel times)
 cd /tmp; export TMPDIR=/tmp
 for l in "$@"; do
   rm -rf /tmp/st_$l
