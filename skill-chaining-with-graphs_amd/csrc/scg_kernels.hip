@@ -1031,6 +1031,7 @@ struct ReduceArgs {
 constexpr int SEG = 16;            // SPEC §5: blocks per first-level segment
 constexpr int RED_WAVES = 16;      // one wave per segment, 16 segments per round
 constexpr int RED_THREADS = 64 * RED_WAVES;
+constexpr int RED_SPW = 2;         // segments per wave and round
 constexpr int RED_COLS = NACT * NF / 4;                              // float4 columns per value function
 constexpr int RED_NCOL = (RED_COLS + 63) / 64;
 
@@ -1242,8 +1243,8 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 // 16 loads in flight, park T_s in LDS, and wave 0 adds the non-empty segments in order, G = ((T_0 + T_1) + ...)
 // — SPEC §5's two levels in one launch.
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
-    __shared__ float4 s_T[RED_WAVES][64];
-    __shared__ int s_cnt[RED_WAVES];
+    __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
+    __shared__ int s_cnt[RED_WAVES * RED_SPW];
     __shared__ int s_x[4][24];         // the commit rows' exchange area
     // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
     const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
@@ -1272,39 +1273,51 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         w_old = *wp;
         sc = *reinterpret_cast<const float4 *>(R.scale + ((live ? i4 : 0) * 4) % NF);     // NF % 4 == 0: no row straddling
     }
-    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES) {
-        const int b0 = (sg0 + wave) * SEG;
-        const int bl = b0 + lane;
-        int c = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
-        const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
+    // A round = RED_SPW segments per wave (32 segments = 512 blocks in all at RED_SPW = 2: the bench size in ONE round): the
+    // counts of all of a wave's segments are read first, then segment after segment its <= 16 slabs with all loads in flight,
+    // and one barrier pair per round (round 2: a round was one segment per wave — two dependent count -> slab round trips and
+    // two barrier pairs at the bench size)
+    for (int sg0 = 0; sg0 < nseg; sg0 += RED_WAVES * RED_SPW) {
+        int cs[RED_SPW];
 #pragma unroll
-        for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
-        float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (mask) {
-            // buffer loads: descriptor = the segment's first slab of this value function (SGPRs), scalar offset = slab u,
-            // vector offset = the lane's column
-            const __amdgpu_buffer_rsrc_t seg = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(slab_k + (size_t)b0 * slab_stride), 0, 0x7fffffff, 0x00020000);
-            u4v v[SEG];
+        for (int j = 0; j < RED_SPW; ++j) {
+            const int bl = (sg0 + j * RED_WAVES + wave) * SEG + lane;
+            cs[j] = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
+        }
 #pragma unroll
-            for (int u = 0; u < SEG; ++u) {
-                v[u] = (u4v){0u, 0u, 0u, 0u};
-                if ((mask >> u) & 1u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(seg, (int)col_off, (int)(u * (unsigned)slab_stride), 0);
-            }
+        for (int j = 0; j < RED_SPW; ++j) {
+            const int b0 = (sg0 + j * RED_WAVES + wave) * SEG;
+            int c = cs[j];
+            const unsigned mask = (unsigned)__ballot(c > 0);     // wave-uniform: which of the segment's blocks hold a slab
 #pragma unroll
-            for (int u = 0; u < SEG; ++u) {
-                if ((mask >> u) & 1u) {
-                    T.x = T.x + __uint_as_float(v[u][0]); T.y = T.y + __uint_as_float(v[u][1]);
-                    T.z = T.z + __uint_as_float(v[u][2]); T.w = T.w + __uint_as_float(v[u][3]);
+            for (int m = 1; m < SEG; m <<= 1) c += __shfl_xor(c, m, 64);
+            float4 T = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (mask) {
+                // buffer loads: descriptor = the segment's first slab of this value function (SGPRs), scalar offset = slab u,
+                // vector offset = the lane's column
+                const __amdgpu_buffer_rsrc_t seg = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char *>(slab_k + (size_t)b0 * slab_stride), 0, 0x7fffffff, 0x00020000);
+                u4v v[SEG];
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) {
+                    v[u] = (u4v){0u, 0u, 0u, 0u};
+                    if ((mask >> u) & 1u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(seg, (int)col_off, (int)(u * (unsigned)slab_stride), 0);
+                }
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) {
+                    if ((mask >> u) & 1u) {
+                        T.x = T.x + __uint_as_float(v[u][0]); T.y = T.y + __uint_as_float(v[u][1]);
+                        T.z = T.z + __uint_as_float(v[u][2]); T.w = T.w + __uint_as_float(v[u][3]);
+                    }
                 }
             }
+            s_T[j * RED_WAVES + wave][lane] = T;
+            if (lane == 0) s_cnt[j * RED_WAVES + wave] = c;
         }
-        s_T[wave][lane] = T;
-        if (lane == 0) s_cnt[wave] = c;
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int u = 0; u < RED_WAVES; ++u) {
+            for (int u = 0; u < RED_WAVES * RED_SPW; ++u) {      // segment order sg0 + u (SPEC §5)
                 const int cu = s_cnt[u];
                 if (cu > 0) {
                     const float4 t = s_T[u][lane];
