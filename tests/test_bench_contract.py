@@ -1,0 +1,54 @@
+"""bench.py's one-line JSON contract, checked on the committed GPU-box lines (no GPU here): the driver, the judge and
+tools/ab_bench.py all parse these fields."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lines():
+    out = []
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_f_bench_*.json")) +
+                    glob.glob(os.path.join(ROOT, "profiles", "r03_rehearsal_*.json"))):
+        out.append((os.path.basename(p), json.load(open(p))))
+    assert len(out) >= 4
+    return out
+
+
+def test_committed_bench_lines_carry_the_contract_fields():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for name, d in _lines():
+        assert d["metric"] == base["metric"], name
+        assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak", name
+        assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None, name
+        assert d["value"] > 1e8 and d["n_gpus"] >= 1 and d["steps"] >= 1, name
+        assert abs(d["value"] - d["config"]["envs_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"], name
+        cfg = d["config"]
+        assert "workload" in cfg and "model" not in cfg and cfg["envs_per_gpu"] == 65536 and cfg["n_options"] == 5, name
+        assert "untimed_ramp_steps" in cfg and cfg["backend"] in ("none", "nccl", "gloo"), name
+        r = d["roofline"]
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0, name
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_ms"] > 0, name
+        assert r["traffic"] is None or (r["traffic"] > 1e7 and "static" in r["traffic_source"]), name
+        m = d["mfma"]
+        assert m["bound"] == "mfma" and m["peak"] == 157.3 and 0.05 < m["frac"] < 1.0, name
+        rk = d["ranks"]
+        assert rk["world_size_seen"] == d["n_gpus"] and rk["ms_per_step_min"] <= rk["ms_per_step_max"], name
+        if d["n_gpus"] == 1:
+            cb = d["cpu_baseline"]
+            assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb, name
+        else:
+            assert d["cpu_baseline"] is None, name
+        if "shared option-Q weights" in cfg["workload"]:
+            ar = rk["allreduce"]
+            assert ar["samples"] >= 1 and ar["bytes"] == (6 * 5 * 1296 + 6) * 4 and ar["mean_us"] > 0, name
+        else:
+            assert rk["allreduce"] is None, name
+
+
+def test_traffic_file_is_consistent_with_the_pmc_summary():
+    t = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+    assert t["traffic_bytes_per_launch"] == int((2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024)
+    assert abs(t["traffic_over_algorithmic"] - t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"]) < 1e-9
+    assert t["algorithmic_bytes_per_launch"] == 65536 * 46
