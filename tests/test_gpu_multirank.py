@@ -85,9 +85,12 @@ def _rank_main(rank, world, port, out_dir):
     ag.clf.copy_(torch.as_tensor(chain_classifiers(m, NOPT), device="cuda:0"))
     ag.enabled_mask = MASK
     ag.W.copy_(torch.as_tensor(random_weights(NOPT + 1, 4, std=0.05), device="cuda:0"))
+    ag.time_allreduce(2)                           # bench.py's hook: event pairs round every second packed all-reduce
     for _ in range(STEPS):
         ag.step_batch()
     torch.cuda.synchronize()
+    ar = ag.time_allreduce(0)
+    assert ar is not None and ar["samples"] == (STEPS + 1) // 2 and 0 < ar["mean_us"] <= ar["max_us"] and ag.allreduce_timing is None
     res = {"W": ag.W.cpu().numpy(), "x": ag.state.x.cpu().numpy(), "option_id": ag.state.option_id.cpu().numpy()}
     # the sharded outer loop: decisions on all-reduced counts, fit on the examples of both ranks
     ag2 = SkillChainingAgent("pinball_empty", 4096, 2, device=0, seed=5, env_id_base=rank * 4096, group=dist.group.WORLD,
