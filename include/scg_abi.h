@@ -165,7 +165,8 @@ int scg_collect_examples(scg_ctx *ctx, uint32_t event_bits, uint8_t *prev_in, in
  * count). Every following scg_step then leaves the per-row example totals behind while it commits its results (the rows are
  * the same), and a matching scg_collect_examples right after it needs one launch instead of two. Results are identical either
  * way; a call that does not match the announcement, or comes without a step in between, takes the two-launch path.
- * event_bits = 0 withdraws the announcement. */
+ * event_bits = 0 withdraws the announcement. prev_in and count are READ by every following scg_step until then (device
+ * pointers kept in the ctx): keep them alive, or withdraw the announcement before freeing them. */
 int scg_arm_collect(scg_ctx *ctx, uint32_t event_bits, const uint8_t *prev_in, int32_t l_pos, int32_t l_neg, const int32_t *count);
 
 /* Gestation (SPEC §4.4; Konidaris & Barto 2009: a new option learns off-policy before it may run). Bit k of gest_mask:
