@@ -47,13 +47,15 @@ constexpr int OFF_Z1 = OFF_INT + 5 * BLOCK_ENVS;               // float2 z1[128]
 // region R, used by one phase at a time:
 //   P, Z  : s[4][128], sn[4][128] (the envs' states) and the edge table [256][8]
 //   E, U1 : W_k staged in A-operand order (12 row tiles x 9 k-blocks x 64 lanes) + per wave CDk[36][16] + ABq[16][AS]
-//   U2    : PT[36][US], CDT[36][US] (one chunk of 64 padded slots = 128 K-steps)
+//   U2    : PT[36][US], CDT[36][US] (one chunk of U2_CH padded slots = 2 U2_CH K-steps)
 constexpr int W_FLOATS = 12 * 9 * 64;
 constexpr int W_TAIL = 12 * 2 * 64 * 4;                        // k-block 8 of every tile sits behind the two float4 groups
 constexpr int AS = 40;                                         // row stride of ABq (floats): 16-byte rows, and the ds_read_b128 of the
                                                                // fold (16-lane groups mixing row groups g, g + 1) conflict-free: 36 gave 2-way
 constexpr int E_TAB_FLOATS = 36 * 16 + 16 * AS;
-constexpr int US = 132;                                        // row stride of the chunk tables (floats)
+constexpr int U2_CH = 72;                                      // U2 chunk: padded slots (9 per wave: 54 of 64 builder lanes busy, and the root's
+                                                               // <= 143 slots are always TWO chunks; 64-slot chunks left a third one of ~8 slots)
+constexpr int US = 2 * U2_CH + 4;                              // row stride of the chunk tables (floats): rows 20 banks apart, operand reads conflict-free
 constexpr int R_TAB = W_FLOATS;                                // private tables start behind the staged W_k
 constexpr int R_S = R_TAB, R_EDGES = R_TAB + 8 * BLOCK_ENVS, R_PITEMS = R_EDGES + MAX_EDGES * 8;   // phases P / Z: inside the table area of waves 0..3 (the helper
                                                                // waves 4..7 use region W and their own tables meanwhile)
@@ -780,8 +782,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         SCG_STAMP(k == 0 ? 7 : 14);   // wait for the other waves
 
         // ---- U2: the block partial (SPEC §5). Padded slots: every action run is padded with null items to a multiple of
-        // 4, run a occupying slots [off4[a], off4[a] + len4[a]). Chunks of 64 slots (128 K-steps, kap = 2 slot + part):
-        //   build  PT[c12][kap] = delta * ABsel, CDT[c34][kap] = CD  (null items: +0); wave w owns slots 8 w .. 8 w + 7
+        // 4, run a occupying slots [off4[a], off4[a] + len4[a]). Chunks of U2_CH = 72 slots (144 K-steps, kap = 2 slot + part):
+        //   build  PT[c12][kap] = delta * ABsel, CDT[c34][kap] = CD  (null items: +0); wave w owns slots 9 w .. 9 w + 8
         //   MFMA   G[a] += PT x CDT^T, groups of 4 items: one MFMA over their real parts, one over the imaginary parts;
         //          the 9 output tiles of action a are dealt to the 8 waves (tile q -> wave (q + a) & 7, so wave a holds two),
         //          accumulators stay in registers for the whole pass and go straight to the block's slab
@@ -798,11 +800,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             for (int s = 0; s < 2; ++s) accU[a][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
         }
         float *ptab = s_R, *ctab = s_R + 36 * US;
-        for (int ch0 = 0; ch0 < off4[NACT]; ch0 += 64) {
+        const int bi9 = lane % 9, cp9 = lane / 9;           // builder lanes of a chunk: (slot 9 wave + bi9, second index cp9 < 6)
+        for (int ch0 = 0; ch0 < off4[NACT]; ch0 += U2_CH) {
             if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
             SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
             {
-                const int slot = 8 * wave + bi, ps = ch0 + slot;
+                const int slot = 9 * wave + bi9, ps = ch0 + slot;
+                const int cp = cp9;                                           // (shadows the 8-item builders' cp in this scope)
                 if (cp < 6 && ps < off4[NACT]) {
                     int a_ = 0;
 #pragma unroll
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
             auto run_u2 = [&](auto aa_c) {
                 constexpr int AA = decltype(aa_c)::value;
-                const int lo = max(off4[AA], ch0), hi = min(off4[AA + 1], ch0 + 64);      // the run's slots in this chunk
+                const int lo = max(off4[AA], ch0), hi = min(off4[AA + 1], ch0 + U2_CH);   // the run's slots in this chunk
                 if (lo >= hi) return;
                 const bool two = wave_u == AA;                   // this wave's tiles: (wave - AA) & 7, and tile 8 on wave AA
                 const float *pa[2], *pb[2];
