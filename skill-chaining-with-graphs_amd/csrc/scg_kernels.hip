@@ -2135,7 +2135,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     A.hist_next = fold ? c->d_hist2[c->hist_parity] : nullptr;
     A.perm = c->d_perm; A.outrec = c->d_outrec;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (c->prof_on && (c->prof_seen++ % c->prof_every) == 0) {
+    if (c->prof_on && (c->prof_seen++ % c->prof_every) == c->prof_every / 2) {     // (not the first launch into an idle queue)
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
         while (c->prof_ev->size() < c->prof_used + 2) {
             hipEvent_t e;
@@ -2269,6 +2269,15 @@ int scg_profile_reset(scg_ctx *c, int32_t enable) {
     c->prof_every = enable > 0 ? enable : 1;
     c->prof_seen = 0;
     c->prof_used = 0;
+    if (enable > 0) {                       // a pool of events up front: creating them lazily cost the first sampled launches of a
+        SCG_ON_DEVICE(c, "scg_profile_reset");      // timed region tens of microseconds of host time in front of an idle queue
+        if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
+        while (c->prof_ev->size() < 64) {
+            hipEvent_t e;
+            SCG_HIP(c, hipEventCreate(&e));
+            c->prof_ev->push_back(e);
+        }
+    }
     return SCG_OK;
 }
 
