@@ -3,9 +3,10 @@
 // One step-batch (SPEC §5) = td_kernel<FUSED> -> reduce_kernel (+ sort_hist / sort_scatter when no env order is
 // prepared). td_kernel: a workgroup = 8 wavefronts owns 128 consecutive positions of the option-sorted env order; two
 // workgroups per CU, <= 128 VGPRs, four waves per SIMD.
-//   phase P  (waves 0..3, one lane per env)  act from qcache, Pinball physics (cell mask -> exact refine -> up to three
-//            candidate edges in registers), reset/bookkeeping, option logic; MEANWHILE waves 4..7 stage W_0, take Z_d^1 of
-//            the entry states, build the root's update list and run U1 of the root pass
+//   phase P  (waves 0..1, one lane per env)  act from qcache, Pinball physics (cell mask -> exact refine; envs without a
+//            candidate edge fly free in place, the (env, edge) pairs of the others are dealt to the lanes of waves 0..3: one
+//            intercept per lane and sub-step, hits combined by ballot), reset/bookkeeping, option logic; MEANWHILE waves 4..7
+//            stage W_0, take Z_d^1 of the entry states, build the root's update list and run U1 of the root pass
 //   phase Z  Z_d^1 = sincospi of the four normalised state variables of s_next -> LDS
 //   phase TD, value function by value function, on the matrix pipe (v_mfma_f32_16x16x4_f32 is bit for bit a k-ordered
 //            fmaf chain, so the CPU oracle reproduces every sum):
@@ -17,8 +18,10 @@
 //         9 output tiles per action dealt over the 8 waves, accumulators stay in registers for the whole pass and
 //         go straight to the block's slab (no cross-wave reduction)
 //   tail     value functions that only have envs ENTERING them here: the same chains on the vector pipe, per wave
-//   reduce_kernel  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G; commit + next env order
-// fit_kernel: SPEC §6 on 8 workgroups x 1024 chains per option behind a counter barrier.
+//   reduce_kernel  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G; commit + next env order (+ an
+//                  announced example trigger's row totals)
+// fit_kernel: SPEC §6 on 8 workgroups x 1024 chains per option behind tagged-word exchanges; a fit whose workgroups cannot run
+// together gives up after a wall-clock wait, leaves its row untouched and raises the ctx's asynchronous status word.
 // Every sum has the pinned order of SPEC §3.1 / §5 / §6 (no atomics on data): the CPU oracle reproduces every bit.
 // No upstream code exists to cite (reference = README.md:1-2); sections cite SPEC.md.
 #include "scg_device.hpp"
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             __builtin_amdgcn_s_sleep(2);                      // (the bound only guards the GPU against a logic error)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    // With learning on, waves 4..7 ("helpers") are idle during phase P (one lane per env on 4 x 32 lanes, latency-bound):
+    // With learning on, waves 4..7 ("helpers") have nothing to do in phase P (one lane per env on waves 0..1, pairs on 0..3):
     // they stage W_0, take Z_d^1 of the entry states, build the root's update list and run U1 of the root pass under it.
     const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
 
