@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _lines():
     out = []
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_f_bench_*.json")) +
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_g_bench_*.json")) +
                     glob.glob(os.path.join(ROOT, "profiles", "r03_rehearsal_*.json"))):
         out.append((os.path.basename(p), json.load(open(p))))
     assert len(out) >= 4
