@@ -9,9 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _lines():
     out = []
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_g_bench_*.json")) +
-                    glob.glob(os.path.join(ROOT, "profiles", "r03_rehearsal_*.json"))):
-        out.append((os.path.basename(p), json.load(open(p))))
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")) +
+                    glob.glob(os.path.join(ROOT, "profiles", "r*_bench_20_steps.json")) +
+                    glob.glob(os.path.join(ROOT, "profiles", "r*_rehearsal_*.json"))):
+        d = json.load(open(p))
+        if "ranks" in d:                                  # lines written since round 3 (earlier rounds' lines predate some fields)
+            out.append((os.path.basename(p), d))
     assert len(out) >= 4
     return out
 
