@@ -21,6 +21,7 @@ def _lines():
 
 def test_committed_bench_lines_carry_the_contract_fields():
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    with_cpu = 0
     for name, d in _lines():
         assert d["metric"] == base["metric"], name
         assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak", name
@@ -38,9 +39,10 @@ def test_committed_bench_lines_carry_the_contract_fields():
         assert m["bound"] == "mfma" and m["peak"] == 157.3 and 0.05 < m["frac"] < 1.0, name
         rk = d["ranks"]
         assert rk["world_size_seen"] == d["n_gpus"] and rk["ms_per_step_min"] <= rk["ms_per_step_max"], name
-        if d["n_gpus"] == 1:
+        if d["n_gpus"] == 1 and d["cpu_baseline"] is not None:      # (None: a line taken with --no-cpu-baseline)
             cb = d["cpu_baseline"]
             assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb, name
+            with_cpu += 1
         else:
             assert d["cpu_baseline"] is None, name
         if "shared option-Q weights" in cfg["workload"]:
@@ -48,6 +50,7 @@ def test_committed_bench_lines_carry_the_contract_fields():
             assert ar["samples"] >= 1 and ar["bytes"] == (6 * 5 * 1296 + 6) * 4 and ar["mean_us"] > 0, name
         else:
             assert rk["allreduce"] is None, name
+    assert with_cpu >= 2                                            # the default and the driver-form line of the final build
 
 
 def test_traffic_file_is_consistent_with_the_pmc_summary():
