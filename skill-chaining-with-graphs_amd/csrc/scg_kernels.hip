@@ -603,10 +603,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
     }
-    // From here on waves 0..3 run at priority 1 and waves 4..7 at 0: waves 0 and 1 build every pass's lists (the other
-    // six wait for them at the next barrier) and the low waves hold the extra U2 tile. Measured against no priority:
+    // From here on waves 0..1 run at priority 1 and the others at 0: waves 0 and 1 build every pass's lists (the other
+    // six wait for them at the next barrier). (Round 2 had waves 0..3 at 1; 0..1 measured +0.3..0.45 % in round 3.) Measured against no priority:
     // +2.0 % env-steps/s; the same for waves 0..1 only; 0 % for waves 4..7, odd waves or one whole workgroup of the CU.
-    if (helpers) { if (wave < HELPER0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    if (helpers) { if (wave < P_WAVES) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
