@@ -1,9 +1,9 @@
 """One-off randomised parity sweep beyond the fixed cases of tests/test_gpu_stress.py: N random configurations (batch size,
 options, map incl. the crowded synthetic ones, masks, option graph, epsilon, seeds), 14-step fused rollouts with acting-only
-steps in between, every output compared bit for bit with the CPU oracle.   Usage: python tools/fuzz_parity.py [N] [seed0]"""
+steps in between, every output compared bit for bit with the CPU oracle.   Usage: python tests/fuzz_parity.py [N] [seed0]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]   # (lives under tests/: it uses the CPU oracle, the checker)
 import numpy as np
 import test_gpu_stress as T
 from util import dense_map, hub_map
