@@ -1,7 +1,7 @@
 """Times the un-fused entry points on one GPU (diagnostic; not part of the bench contract)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+sys.path[:0] = [ROOT]
 import numpy as np, torch
 import skill_chaining_with_graphs_amd as scg
 from skill_chaining_with_graphs_amd.core import ScgContext
