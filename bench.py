@@ -119,7 +119,7 @@ def cpu_baseline(seconds_target=15.0):
     clf = chain_discs(m, N_OPTIONS)
 
     def timed(threads, budget):
-        n = 128 * threads                     # one 128-env block (SPEC §5) per thread
+        n = 256 * threads                     # one 256-env block (SPEC §5) per thread
         orc = sc_oracle.Oracle(m, fourier_scale_table(), n_envs=n, n_options=N_OPTIONS, seed=0,
                                enabled_mask=sum(1 << k for k in range(1, N_OPTIONS + 1)), n_threads=threads, **HP)
         st = sc_oracle.new_state(n, m)
@@ -143,7 +143,7 @@ def cpu_baseline(seconds_target=15.0):
     v1, n1, s1, d1 = timed(1, seconds_target / 3.0)
     vc, nc, sc, dc = timed(cores, seconds_target * 2.0 / 3.0)
     return {"value": vc, "unit": "env-steps/s", "cores": cores, "kind": "port", "single_thread_value": v1,
-            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, scalar fmaf chains, OpenMP over 128-env blocks; `cores` = "
+            "sample": f"in-repo CPU oracle (oracle/sc_oracle.c, scalar fmaf chains, OpenMP over 256-env blocks; `cores` = "
                       f"the CPUs this process may use: affinity mask capped by the cgroup quota), same workload: "
                       f"{nc} envs x {sc} step-batches on {cores} threads in {dc:.1f} s; {n1} envs x {s1} step-batches "
                       f"on 1 thread in {d1:.1f} s; the upstream reference ships no code to time"}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 1
+#define SCG_ABI_VERSION 2
 #define SCG_NUM_ACTIONS 5
 #define SCG_FOURIER_ORDER 5
 #define SCG_NUM_FEATURES 1296      /* (order+1)^4 */
@@ -61,7 +61,7 @@ typedef struct {
 #define SCG_STEP_APPLY 2u        /* apply it to W in the same call (single-rank path) */
 
 int scg_abi_version(void);
-int scg_block_envs(void);            /* SPEC §5 block size this library was built with: 128 envs (one 8-wavefront workgroup) */
+int scg_block_envs(void);            /* SPEC §5 block size this library was built with: 256 envs (one 16-wavefront workgroup) */
 const char *scg_strerror(int status);
 const char *scg_last_error(const scg_ctx *ctx);
 
@@ -185,10 +185,16 @@ int scg_set_gestation(scg_ctx *ctx, uint32_t gest_mask, int32_t *succ_counts);
  * process) a workgroup may be kept off it. A missing partner is waited for scg_set_fit_timeout seconds of wall clock
  * (default 2 s), then the fit of that problem is abandoned: its row of `w` keeps the values it had, never a partial
  * result or a NaN. Word layout: SCG_ASYNC_FIT_TIMEOUT | 0x100 << (problem index & 15).
+ * The step kernel is the second: the wavefront subsets of a workgroup hand work to each other through counters in LDS and
+ * poll them with a bound (2^20 rounds; every awaited count is produced by wavefronts that never wait on the waiter, so
+ * the bound is only reached through a logic error or a hung wavefront). A poll that runs out raises
+ * SCG_ASYNC_STEP_HANDOFF: that block's partial gradients are dropped (its slab counts read 0) and the step's other
+ * outputs for the block's envs are unspecified — the state must be restored from a checkpoint.
  *   scg_async_status      the word (optional out) and its status; `synchronize` != 0 waits for `stream` first, which
  *                         makes the answer final for everything launched on it so far
  *   scg_decode_async_word the same mapping word -> status + text without a ctx (pure host code) */
 #define SCG_ASYNC_FIT_TIMEOUT 0x1u
+#define SCG_ASYNC_STEP_HANDOFF 0x2u
 int scg_async_status(scg_ctx *ctx, void *stream, int32_t synchronize, uint32_t *word_out);
 int scg_clear_async_error(scg_ctx *ctx);
 int scg_set_fit_timeout(scg_ctx *ctx, double seconds);

@@ -18,7 +18,7 @@ extern "C" {
 
 #define SCO_NACT 5
 #define SCO_NF 1296
-#define SCO_BLOCK_ENVS 128          /* SPEC §5: envs per block */
+#define SCO_BLOCK_ENVS 256          /* SPEC §5: envs per block */
 #define SCO_CLF_STRIDE 8
 
 typedef struct {

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCO_LIB") or os.path.join(_HERE, "libsc_oracle.so")   # SCO_LIB: the sanitizer build
-NACT, NF, CLF_STRIDE, BLOCK_ENVS = 5, 1296, 8, 128
+NACT, NF, CLF_STRIDE, BLOCK_ENVS = 5, 1296, 8, 256
 
 
 class Params(C.Structure):

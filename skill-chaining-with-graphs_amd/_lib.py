@@ -17,6 +17,9 @@ CLF_STRIDE = 8
 
 STEP_LEARN = 1
 STEP_APPLY = 2
+ABI_VERSION = int(os.environ.get("SCG_LIB_ABI", "2"))   # include/scg_abi.h SCG_ABI_VERSION (SCG_LIB_ABI: A/B runs against a historical build)
+ASYNC_FIT_TIMEOUT = 0x1
+ASYNC_STEP_HANDOFF = 0x2
 
 
 class ScgError(RuntimeError):
@@ -94,12 +97,20 @@ def load() -> C.CDLL:
             f"{os.path.dirname(LIB_PATH)}`). There is no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
+    try:
+        ver = int(lib.scg_abi_version())
+    except AttributeError:
+        raise ScgError(f"{LIB_PATH} does not export scg_abi_version: not a libscg_hip.so") from None
+    if ver != ABI_VERSION:
+        raise ScgError(f"{LIB_PATH} implements ABI version {ver}, this binding expects {ABI_VERSION} "
+                       "(include/scg_abi.h): rebuild the library (a stale .so?)")
     for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ScgError(f"{LIB_PATH} does not export {name} although it reports ABI version {ver}: rebuild it") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.scg_abi_version() != 1:
-        raise ScgError("libscg_hip.so ABI version mismatch")
     _lib = lib
     return lib
 

@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import dist as _dist
-from ._lib import CLF_STRIDE, NUM_ACTIONS, NUM_FEATURES
+from ._lib import CLF_STRIDE, NUM_ACTIONS, NUM_FEATURES, ScgError
 from .core import EnvState, ScgContext
 from .maps import PinballMap, load_map
 from .option import Option
@@ -66,8 +66,9 @@ class SkillChainingAgent:
         """Call after a step_batch while option k is being created: envs whose step ended inside option k's target
         region (goal disc if parent[k] = 0, else the parent's initiation set, on the step they ENTER it) append their
         last l_pos ring states as positives and the l_neg states before those as negatives to option k's example
-        buffer. Selection, compaction and the gather run in ONE kernel on the device (SPEC §7): nothing is read back,
-        the host is not in the per-step path; examples_held(k) fetches the count when the outer loop wants it."""
+        buffer. Selection, compaction and the gather run on the device (SPEC §7; one launch behind the step, whose
+        commit rows leave the row totals of the announced trigger): nothing is read back, the host is not in the
+        per-step path; examples_held(k) fetches the count when the outer loop wants it."""
         xy, lab, cnt, prev = self._ex_buffers(k)
         parent = int(self.ctx.parents[k])
         self.ctx.collect_examples(1 if parent == 0 else (1 << parent), prev, l_pos, l_neg, xy.view(-1), lab, cnt)
@@ -97,7 +98,17 @@ class SkillChainingAgent:
         if self.group is not None:           # fit on the examples of ALL ranks (rank order): identical classifiers everywhere
             xy, lab = _dist.allgather_rows(xy.contiguous(), self.group), _dist.allgather_rows(lab.contiguous(), self.group)
         clf = self.options[k].initiation_classifier
-        clf.fit(xy.contiguous(), lab.contiguous(), iters=iters, lr=lr, l2=l2)
+        err = None
+        try:
+            clf.fit(xy.contiguous(), lab.contiguous(), iters=iters, lr=lr, l2=l2)
+        except ScgError as e:                # the fit gave up on the device (sticky status word): the row is untouched
+            err = e
+        if self.group is not None:           # a give-up is rank-local: agree on it before anyone acts on the classifier,
+            bad = _dist.allreduce_sum_int(1 if err else 0, self.group, self.W.device)      # or the peers hang in the next collective
+            if bad and err is None:
+                raise ScgError(f"create_option({k}): the initiation-set fit gave up on {bad} other rank(s); no rank enables the option")
+        if err is not None:
+            raise err
         self.W[k].copy_(self.W[0])
         if gestation > 0:
             self._gest_need[k] = int(gestation)

@@ -73,6 +73,7 @@ class ScgContext:
         return t
 
     def close(self) -> None:
+        self._step_args = self._step_keep = self._armed = None
         if getattr(self, "_ctx", None) and self._ctx.value:
             self.lib.scg_destroy(self._ctx)
             self._ctx = C.c_void_p()
@@ -97,8 +98,11 @@ class ScgContext:
              learn: bool = True, apply: bool = True) -> None:
         # the validated, pre-marshalled pointer arguments of the last call are reused while the same tensors come back
         # (one step is two kernel launches: the host side of a call matters in short runs)
-        key = (id(st), id(st.x), id(st.y), id(st.vx), id(st.vy), id(st.option_id), id(st.opt_steps), id(st.ep_steps),
-               id(st.qcache), id(st.action), id(st.reward), id(st.done), id(W), id(clf), st.x.data_ptr(), W.data_ptr())
+        # (the key holds every tensor's storage address, not only the Python ids: `.data =` / `set_()` on the same object
+        # swaps the storage under an unchanged id)
+        key = (id(st), id(W), id(clf), st.x.data_ptr(), st.y.data_ptr(), st.vx.data_ptr(), st.vy.data_ptr(),
+               st.option_id.data_ptr(), st.opt_steps.data_ptr(), st.ep_steps.data_ptr(), st.qcache.data_ptr(),
+               st.action.data_ptr(), st.reward.data_ptr(), st.done.data_ptr(), W.data_ptr(), clf.data_ptr())
         cached = getattr(self, "_step_args", None)
         if cached is not None and cached[0] == key:
             flags = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
@@ -129,6 +133,7 @@ class ScgContext:
 
     def invalidate_order(self) -> None:
         """Tell the library that option ids were written outside scg_step (reset, restore): re-sort next step."""
+        self._step_args = self._step_keep = None
         self._call("scg_invalidate_order")
 
     def set_option_parents(self, parents) -> None:
@@ -144,6 +149,7 @@ class ScgContext:
     def set_trace_buffers(self, ring_len: int):
         """Allocate and attach the trajectory ring + event buffers; returns (ring_x, ring_y, events, ev_len).
         ring_len must be a power of two; ring_len = 0 detaches."""
+        self._armed = None                 # the library drops an announced trigger with the buffers it refers to
         if ring_len == 0:
             self._call("scg_set_trace_buffers", None, None, 0, None, None)
             self._trace = None
@@ -181,7 +187,11 @@ class ScgContext:
                          ex_xy: torch.Tensor, ex_label: torch.Tensor, count: torch.Tensor, rearm: bool = True) -> None:
         """SPEC §7 device-side trigger: envs whose events byte has one of `event_bits` set (with prev_in: on the step the
         bit goes up) append their most recent ring states to ex_xy[cap, 2] / ex_label[cap] behind the count[0] examples
-        already there (device int32[1], in/out). One launch, nothing comes back to the host."""
+        already there (device int32[1], in/out). Two small launches (row totals, then prefix + gather) — one when the
+        trigger was announced (`rearm`, scg_arm_collect: the step's own commit rows then leave the row totals); nothing
+        comes back to the host. With `rearm` the library keeps the RAW device pointers of prev_in and count and reads
+        them inside every later scg_step until disarm_collect() / set_trace_buffers(): this object holds references to
+        both tensors for exactly that long, so dropping yours cannot leave the step reading freed memory."""
         if getattr(self, "_trace", None) is None:
             raise ScgError("collect_examples: trace buffers are not attached (set_trace_buffers)")
         cap = ex_label.numel()
@@ -195,9 +205,13 @@ class ScgContext:
                    _ptr(count), cap, self._stream())
         if rearm:            # the same trigger will come again after the next step: let that step leave the row totals behind
             self._call("scg_arm_collect", C.c_uint32(event_bits), _ptr(prev_in), l_pos, l_neg, _ptr(count))
+            self._armed = (prev_in, count)       # keeps the announced buffers alive while the library holds their addresses
+        else:
+            self.disarm_collect()
 
     def disarm_collect(self) -> None:
         self._call("scg_arm_collect", C.c_uint32(0), None, 0, 0, None)
+        self._armed = None
 
     def set_gestation(self, gest_mask: int) -> torch.Tensor:
         """SPEC §4.4: options in gestation (known, never selected, learning off-policy). Returns the device int32[n_vf]

@@ -10,8 +10,8 @@ namespace scg {
 
 constexpr int NACT = 5;
 constexpr int NF = 1296;
-constexpr int BLOCK_ENVS = 128;               // SPEC §5 geometry: envs per block = per workgroup
-constexpr int WAVES = 8;                      // wavefronts per workgroup (two workgroups per CU: four waves per SIMD)
+constexpr int BLOCK_ENVS = 256;               // SPEC §5 geometry: envs per block = per workgroup
+constexpr int WAVES = 16;                     // wavefronts per workgroup (one workgroup per CU: four waves per SIMD)
 constexpr int LIST_WAVES = BLOCK_ENVS / 64;   // waves that ballot the workgroup's env flags
 constexpr int THREADS = WAVES * 64;
 constexpr int MAX_EDGES = 256;

@@ -1,23 +1,9 @@
 // scg_kernels.hip — gfx950 kernels + the C-ABI of include/scg_abi.h.
 //
 // One step-batch (SPEC §5) = td_kernel<FUSED> -> reduce_kernel (+ sort_hist / sort_scatter when no env order is
-// prepared). td_kernel: a workgroup = 8 wavefronts owns 128 consecutive positions of the option-sorted env order; two
-// workgroups per CU, <= 128 VGPRs, four waves per SIMD.
-//   phase P  (waves 0..1, one lane per env)  act from qcache, Pinball physics (cell mask -> exact refine; envs without a
-//            candidate edge fly free in place, the (env, edge) pairs of the others are dealt to the lanes of waves 0..3: one
-//            intercept per lane and sub-step, hits combined by ballot), reset/bookkeeping, option logic; MEANWHILE waves 4..7
-//            stage W_0, take Z_d^1 of the entry states, build the root's update list and run U1 of the root pass
-//   phase Z  Z_d^1 = sincospi of the four normalised state variables of s_next -> LDS
-//   phase TD, value function by value function, on the matrix pipe (v_mfma_f32_16x16x4_f32 is bit for bit a k-ordered
-//            fmaf chain, so the CPU oracle reproduces every sum):
-//     E   Q_k(s_next, .) of 8 items per wave-iteration: T[(a,c12)][item re|im] = W_k (180 x 36, staged in LDS in
-//         A-operand order, one ds_read_b128 per four MFMAs) x CD (36 x 16, from a per-wave LDS table) = 108 MFMAs, then
-//         per lane 48 fmas with the AB factors and a 3-stage butterfly (SPEC §3.1)
-//     U1  Q_k(s, a_t) per action run: the same contraction on the 3 row tiles of action a_t
-//     U2  the block partial G_b,k[a] (36 x 36) += P (36 x 2n, delta-scaled AB factors) x C^T (2n x 36, CD factors):
-//         9 output tiles per action dealt over the 8 waves, accumulators stay in registers for the whole pass and
-//         go straight to the block's slab (no cross-wave reduction)
-//   tail     value functions that only have envs ENTERING them here: the same chains on the vector pipe, per wave
+// prepared). td_kernel (scg_step_kernel.hpp): a workgroup = 16 wavefronts owns 256 consecutive positions of the
+// option-sorted env order and the whole LDS of its CU; <= 128 VGPRs, four waves per SIMD; the root value function and the
+// block's option run as ONE merged pass on shared tables of Fourier factors.
 //   reduce_kernel  slabs -> 16-block segment sums -> G, n_k, W += alpha/n_k * scale * G; commit + next env order (+ an
 //                  announced example trigger's row totals)
 // fit_kernel: SPEC §6 on 8 workgroups x 1024 chains per option behind tagged-word exchanges; a fit whose workgroups cannot run
@@ -37,69 +23,6 @@
 using namespace scg;
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------
-constexpr int P_WAVES = BLOCK_ENVS / 64;      // phase P: one lane per env on full waves
-constexpr int HELPER0 = WAVES / 2;            // waves HELPER0.. work under phase P (learning steps)
-constexpr int P_POOL = HELPER0;               // waves 0..P_POOL-1 share the physics' (env, edge) pair groups
-static_assert(P_WAVES == 2, "the pair-group owner lookup below is written for two env waves");
-// LDS map of the step kernel (bytes). 8 wavefronts per workgroup, two workgroups per CU (80 KB each).
-constexpr int OFF_RC = 0;                                      // float r0,c0,ro,co (per env), rk,ck (per env, this pass) [128]
-constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia [128]
-constexpr int OFF_Z1 = OFF_INT + 5 * BLOCK_ENVS;               // float2 z1[128][2][4]: Z_d^1 of s and s_next
-// region R, used by one phase at a time:
-//   P, Z  : s[4][128], sn[4][128] (the envs' states) and the edge table [256][8]
-//   E, U1 : W_k staged in A-operand order (12 row tiles x 9 k-blocks x 64 lanes) + per wave CDk[36][16] + ABq[16][AS]
-//   U2    : PT[36][US], CDT[36][US] (one chunk of U2_CH padded slots = 2 U2_CH K-steps)
-constexpr int W_FLOATS = 12 * 9 * 64;
-constexpr int W_TAIL = 12 * 2 * 64 * 4;                        // k-block 8 of every tile sits behind the two float4 groups
-constexpr int AS = 40;                                         // row stride of ABq (floats): 16-byte rows, and the ds_read_b128 of the
-                                                               // fold (16-lane groups mixing row groups g, g + 1) conflict-free: 36 gave 2-way
-constexpr int E_TAB_FLOATS = 36 * 16 + 16 * AS;
-constexpr int U2_CH = 72;                                      // U2 chunk: padded slots (9 per wave: 54 of 64 builder lanes busy, and the root's
-                                                               // <= 143 slots are always TWO chunks; 64-slot chunks left a third one of ~8 slots)
-constexpr int US = 2 * U2_CH + 4;                              // row stride of the chunk tables (floats): rows 20 banks apart, operand reads conflict-free
-constexpr int R_TAB = W_FLOATS;                                // private tables start behind the staged W_k
-constexpr int R_S = R_TAB, R_EDGES = R_TAB + 8 * BLOCK_ENVS, R_PITEMS = R_EDGES + MAX_EDGES * 8;   // phases P / Z: inside the table area of waves 0..3 (the helper
-                                                               // waves 4..7 use region W and their own tables meanwhile)
-constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
-constexpr int R_FLOATS = cmax3(W_FLOATS + WAVES * E_TAB_FLOATS, 2 * 36 * US, R_EDGES + MAX_EDGES * 8);
-constexpr int OFF_R = OFF_Z1 + BLOCK_ENVS * 2 * 4 * 8;
-constexpr int OFF_ELIST = OFF_R + R_FLOATS * 4;                // uint16 eval list[128]
-constexpr int OFF_ULIST = OFF_ELIST + BLOCK_ENVS * 2;          // uint16 update list[128] (5 action runs)
-constexpr int OFF_MAXQ = OFF_ULIST + BLOCK_ENVS * 2;           // float maxq[128] (per env)
-constexpr int OFF_QSA = OFF_MAXQ + BLOCK_ENVS * 4;             // float qsa[128] (per update-list position)
-constexpr int OFF_ENV = OFF_QSA + BLOCK_ENVS * 4;              // int env[128]: env index of each block slot
-constexpr int OFF_CLF = OFF_ENV + BLOCK_ENVS * 4;              // float clf[6][8]
-constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[32]
-#ifdef SCG_STAMPS
-constexpr int OFF_STAMP = OFF_MISC + 128;                      // unsigned stamp[32] (diagnostic build)
-constexpr int LDS_BYTES = OFF_STAMP + 128;
-#else
-constexpr int LDS_BYTES = OFF_MISC + 128;
-#endif
-static_assert(LDS_BYTES <= 80 * 1024, "LDS budget: two workgroups per CU");
-static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0 && (R_EDGES * 4) % 16 == 0, "LDS alignment");
-static_assert(8 * BLOCK_ENVS + MAX_EDGES * 8 + P_WAVES * PITEMS <= HELPER0 * E_TAB_FLOATS, "states + edges + the physics pair lists fit the table area of the waves below the helpers");
-
-enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
-
-// Diagnostic build only (make stamps -> libscg_hip_stamps.so, tools/stamp_report.py): wave 0 of every
-// workgroup accumulates s_memtime deltas per kernel section into A.stamps[block][section]. The shipped
-// library is built without SCG_STAMPS and contains none of this.
-#ifdef SCG_STAMPS
-
-#define SCG_STAMP(SEC)                                                                   \
-    do {                                                                                 \
-        if (MODE == MODE_FUSED && A.stamps && tid == 0) {                                \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
-            s_stamp[(SEC)] += (unsigned)(t_ - stamp_prev);                               \
-            stamp_prev = t_;                                                             \
-        }                                                                                \
-    } while (0)
-#else
-#define SCG_STAMP(SEC) do { } while (0)
-#endif
 
 template <typename T>
 __device__ __forceinline__ void gstore(T *p, T v) { *p = v; }
@@ -139,6 +62,7 @@ struct StepArgs {
     float *slabs;                  // [nblk][n_vf][5][1296]
     int32_t *cnts;                 // [nblk][n_vf]
     unsigned long long *stamps;    // diagnostic build only
+    uint32_t *async_word;          // host-visible sticky status word (a hand-off poll that runs out is reported there)
     int32_t n, n_vf, k_lo, k_hi;
     uint32_t enabled, learn;
     uint32_t gest;                 // SPEC §4.4: options in gestation (classifier known, not selectable, learning off-policy)
@@ -215,790 +139,7 @@ __device__ __forceinline__ void item_tree_sum(float (&q)[M]) {
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *s_s = reinterpret_cast<float *>(smem + OFF_R) + R_S;        // [8][128]: s then sn   (region R, phases P and Z)
-    float *s_edges = reinterpret_cast<float *>(smem + OFF_R) + R_EDGES;  // [n_edges][8]        (region R, phase P)
-    uint32_t *s_pitems = reinterpret_cast<uint32_t *>(smem + OFF_R) + R_PITEMS;   // [P_WAVES][PITEMS] (env, edge) pairs of the physics
-    float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
-    float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
-    float *s_rk = s_co + BLOCK_ENVS, *s_ck = s_rk + BLOCK_ENVS;       // reward / continuation of the pass's value function
-    uint8_t *s_a = reinterpret_cast<uint8_t *>(smem + OFF_INT);
-    uint8_t *s_ot = s_a + BLOCK_ENVS, *s_on = s_ot + BLOCK_ENVS;
-    uint8_t *s_gs = s_on + BLOCK_ENVS;      // bit k: gestating option k holds s in its initiation set (off-policy item)
-    uint8_t *s_ia = s_gs + BLOCK_ENVS;      // bit 0: goal; bit k: in_k(s')
-    float2 *s_z1 = reinterpret_cast<float2 *>(smem + OFF_Z1);
-    float *s_R = reinterpret_cast<float *>(smem + OFF_R);
-    uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
-    uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
-    float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
-    float *s_qsa = reinterpret_cast<float *>(smem + OFF_QSA);
-    float *s_W = s_R;                                                   // region W = the head of region R
-    int *s_env = reinterpret_cast<int *>(smem + OFF_ENV);
-    float *s_clf = reinterpret_cast<float *>(smem + OFF_CLF);
-    int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    const int e0 = b * BLOCK_ENVS;
-    const int nb = min(BLOCK_ENVS, A.n - e0);
-    const int N = A.n;
-#ifdef SCG_STAMPS
-    unsigned *s_stamp = reinterpret_cast<unsigned *>(smem + OFF_STAMP);
-    if (tid < 32) s_stamp[tid] = 0;
-    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
-#endif
-
-    if (MODE == MODE_FUSED) {
-        for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
-        if (tid == 0) { s_misc[31] = 1; s_misc[30] = 1; s_misc[29] = 0; s_misc[28] = 0; s_misc[25] = 0; s_misc[24] = 0; }  // [31]/[30] bit k: some env here has an item /
-                                                           // an UPDATE item for VF k; [29]/[28]: hand-off counters
-        if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
-        block_lds_sync();
-    }
-
-    // Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
-    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
-    // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
-    // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
-    // imaginary-part column at 8 h + 4 + i.
-    const int n16 = lane & 15, g = lane >> 4;
-    const int bi = lane & 7, cp = lane >> 3;
-    const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
-    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
-    const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
-    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
-    const float *ab_lane = abq + n16 * AS + 4 * g;
-
-    // private tables of one 8-item column block: items lst[i0 .. i0 + cnt) (a short block repeats its last item),
-    // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
-    auto build_block = [&](const uint16_t *lst, int i0, int cnt, int sg) {
-        if (cp < 6) {
-            const int it = lst[i0 + min(bi, cnt - 1)];
-            float2 ab[6], cd[6];
-            item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                abq[bcol * AS + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * AS + 6 * c + cp] = -ab[c].y;
-                cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
-            }
-        }
-    };
-
-    // A operands come from the staged W_k, per row tile two ds_read_b128 (k-blocks 0..3, 4..7) and one ds_read_b32
-    // (k-block 8): the kernel stays below 128 VGPRs, four waves share a SIMD, and while one wave builds tables or
-    // folds its accumulators another one keeps the matrix pipe busy
-    const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane;
-    const float *w8 = s_W + W_TAIL + lane;
-
-    // U1: Q_k(s, a_t) of the update items, per action run, 8 items per wave-iteration: the contraction of E on the 3 row
-    // tiles that hold action a's rows -> s_qsa[list position]. The column blocks of all runs are dealt to `nw` waves.
-    auto run_u1 = [&](int wv, int nw, const int (&rl)[NACT], const int (&ro)[NACT], int base) {
-#pragma unroll 1
-        for (int a = 0; a < NACT; ++a) {
-            const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
-            const int cnt = rl[a];
-            const uint16_t *lst = s_ulist + ro[a];
-            for (int cb = ((wv - base) & (nw - 1)); 8 * cb < cnt; cb += nw) {
-                build_block(lst, 8 * cb, min(8, cnt - 8 * cb), 0);
-                wave_lds_sync();
-                float B[9];
-#pragma unroll
-                for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-                float qs = 0.0f;
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt) {
-                    const int t = t0 + tt;
-                    const f4v a0 = w4[(t * 2) * 64], a1 = w4[(t * 2 + 1) * 64];
-                    const float a8 = w8[t * 64];
-                    f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
-                    const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
-                    const bool in = r0 >= 0 && r0 < 36;
-                    const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * AS + (in ? r0 : 0));
-                    float xq = qs;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) xq = fmaf(c[v], ab4[v], xq);
-                    qs = in ? xq : qs;
-                }
-                float qo[1] = {qs};
-                item_tree_sum<1>(qo);
-                if (out_lane && 8 * cb + ocol_item < cnt) s_qsa[ro[a] + 8 * cb + ocol_item] = qo[0];
-                wave_lds_sync();
-            }
-            base += (cnt + 7) >> 3;
-        }
-    };
-    // W_k -> region W in A-operand order (12 row tiles of the 180 x 36 matrix; entry (tile t, k-block kb, lane (n16, g)) =
-    // W[16 t + n16][9 g + kb], rows >= 180 zero; per tile and lane the k-blocks 0..3 and 4..7 form two float4 — one
-    // ds_read_b128 feeds four MFMAs — and k-block 8 sits apart), by `nth` threads with index `ht`. One coalesced read per
-    // workgroup instead of a 27 KB gather per wave: every workgroup of the chip wants the same 26 KB at the same moment,
-    // and the L2 channels holding them were the bottleneck.
-    auto stage_w = [&](const float *Wk, int ht, int nth) {
-        // one thread per DESTINATION float4 (row tile t, k-block half hk, lane (nn, gg)): its four values W[16 t + nn][9 gg + 4 hk ..
-        // + 3] are consecutive in the source row — a 16-byte load at a 4-byte-aligned address — and go out as one linear
-        // ds_write_b128. (Round 2 walked the SOURCE float4s and scattered each into four places: ~45 instructions of index
-        // arithmetic per float4 and 2.5-way bank conflicts on the stores.)
-        struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
-        f4v *dst4 = reinterpret_cast<f4v *>(s_W);
-        for (int d = ht; d < 12 * 2 * 64; d += nth) {
-            const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
-            f4v v = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-            if (row < NACT * 36) {
-                const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
-                v = (f4v){w.x, w.y, w.z, w.w};
-            }
-            dst4[d] = v;
-        }
-        for (int z = ht; z < 12 * 64; z += nth) {                                 // k-block 8 of every tile
-            const int ln = z & 63, row = 16 * (z >> 6) + (ln & 15);
-            s_W[W_TAIL + z] = row < NACT * 36 ? Wk[row * 36 + 9 * (ln >> 4) + 8] : 0.0f;
-        }
-    };
-    // counters in LDS for hand-offs between SUBSETS of the workgroup's waves (s_barrier takes all eight): a producer
-    // publishes with lds_arrive, a consumer polls with lds_await. Every awaited count is reached by waves that never
-    // wait on the waiter, so the polls terminate.
-    auto lds_arrive = [&](int *ctr, int amount) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == __builtin_ctzll(__ballot(true))) atomicAdd(ctr, amount);
-    };
-    auto lds_await = [&](int *ctr, int want) {
-        for (int spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want && spins < (1 << 20); ++spins)
-            __builtin_amdgcn_s_sleep(2);                      // (the bound only guards the GPU against a logic error)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    // With learning on, waves 4..7 ("helpers") have nothing to do in phase P (one lane per env on waves 0..1, pairs on 0..3):
-    // they stage W_0, take Z_d^1 of the entry states, build the root's update list and run U1 of the root pass under it.
-    const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
-
-    // ------------------------------------------------------------------ phase P
-    if (helpers && wave < P_WAVES) __builtin_amdgcn_s_setprio(2);   // phase P is the critical path: its waves issue
-                                                                     // ahead of the helper waves (which have slack)
-    if (wave < P_WAVES) {                             // one lane per env on P_WAVES full waves; the physics deals (env, edge)
-        const int i = tid;                            // pairs to the lanes of the same wave (pinball_step_wave)
-        const bool valid = i < nb;
-        const int e = (MODE == MODE_FUSED && A.perm && valid) ? A.perm[e0 + i] : e0 + i;
-        s_env[i] = e;
-        if (MODE == MODE_FUSED) {
-            uint32_t u[4] = {0u, 0u, 0u, 0u};
-            int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
-            float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
-            if (valid) {
-                // act (SPEC §2, §4.3)
-                const uint64_t g = (uint64_t)(A.env_base + e);
-                philox4x32_10((uint32_t)g, (uint32_t)(A.t & 0xffffffffu), (uint32_t)(A.t >> 32), 0u,
-                              (uint32_t)(A.seed & 0xffffffffu), (uint32_t)(A.seed >> 32), u);
-                const bool explore = (float)(u[0] >> 8) * 0x1p-24f < A.epsilon;
-                const int a_rand = (int)__umulhi(u[1], 5u);
-                int a_greedy = 0;
-                float best = A.qcache[e];
-#pragma unroll
-                for (int a = 1; a < NACT; ++a) {
-                    const float q = A.qcache[(size_t)a * N + e];
-                    if (q > best) { best = q; a_greedy = a; }
-                }
-                a = explore ? a_rand : a_greedy;
-                SCG_STAMP(16);                                        // P: perm + qcache gathers, Philox, action
-                sx = A.x[e]; sy = A.y[e]; svx = A.vx[e]; svy = A.vy[e];
-                ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];   // early: latency hides under the physics
-                s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
-                s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
-                s_a[i] = (uint8_t)a;
-            }
-            if (helpers) lds_arrive(&s_misc[29], __popcll(__ballot(valid)));      // state and action of these envs are out
-            // physics (SPEC §1.3), the whole wave together
-            bool goal;
-            SCG_STAMP(17);                                        // P: state gathers
-            // the envs' own wave settles free flight and lists the (env, candidate edge) pairs of the others in groups of 64;
-            // the groups of BOTH env waves are then dealt to waves 0..P_POOL-1 (a wave whose 64 envs sit near walls would
-            // otherwise need two or three rounds of 20 sub-steps while its neighbours idle)
-            bool par;
-            float *xs_mine = s_s + 4 * BLOCK_ENVS + wave * 64;
-            const int groups = pinball_wave_prepare_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal, par,
-                                                        s_pitems + wave * PITEMS, xs_mine, BLOCK_ENVS);
-            if (lane == 0) s_misc[22 + wave] = groups;
-            lds_arrive(&s_misc[24], 1);
-            SCG_STAMP(18);                                        // P: physics, own part (refinement, free flight, pair lists)
-            {
-                lds_await(&s_misc[24], P_WAVES);
-                int gsum[P_WAVES + 1];
-                gsum[0] = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[22 + w2];
-                for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
-                    int owner = 0;
-#pragma unroll
-                    for (int w2 = 1; w2 < P_WAVES; ++w2) owner += q >= gsum[w2] ? 1 : 0;
-                    pinball_wave_group(s_edges, A.ms, s_pitems + owner * PITEMS + 64 * (q - (owner ? gsum[1] : 0)),
-                                       s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
-                }
-                lds_arrive(&s_misc[25], 1);
-                lds_await(&s_misc[25], P_POOL);
-            }
-            const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
-            SCG_STAMP(2);                                         // P: physics, the pooled pair groups + hand-offs
-            if (valid) {
-                // bookkeeping (SPEC §1.4)
-                const int eps1 = ep0 + 1;
-                const bool timeout = !goal && eps1 >= A.max_ep;
-                const int dn = goal ? 1 : (timeout ? 2 : 0);
-                float nx = sx, ny = sy, nvx = svx, nvy = svy;
-                if (dn) {
-                    const uint32_t si = __umulhi(u[2], (uint32_t)A.ms.n_starts);
-                    nx = A.starts[2 * si]; ny = A.starts[2 * si + 1]; nvx = 0.0f; nvy = 0.0f;
-                }
-                s_s[4 * BLOCK_ENVS + i] = nx; s_s[5 * BLOCK_ENVS + i] = ny;
-                s_s[6 * BLOCK_ENVS + i] = nvx; s_s[7 * BLOCK_ENVS + i] = nvy;
-                // options (SPEC §4.2), branch-free: membership bit masks of s' and s_next over all options
-                // (classifier rows come from LDS), then the success / failure / selection rules on the masks
-                unsigned inA = 0, inB = 0, inS = 0;   // bit k: in_k(s'), in_k(s_next); gestating k only: in_k(s)
-                const unsigned known = A.enabled | A.gest;
-#pragma unroll
-                for (int k = 1; k < MAX_VF; ++k) {
-                    if (k < A.n_vf && ((known >> k) & 1u)) {
-                        const float *w = s_clf + CLF_STRIDE * k;
-                        if (clf_z(w, sx, sy) > 0.0f) inA |= 1u << k;
-                        if (clf_z(w, nx, ny) > 0.0f) inB |= 1u << k;
-                        if (((A.gest >> k) & 1u) && clf_z(w, s_s[0 * BLOCK_ENVS + i], s_s[1 * BLOCK_ENVS + i]) > 0.0f) inS |= 1u << k;
-                    }
-                }
-                bool keep = false;
-                float ro = 0.0f, co = 0.0f;
-                if (o >= 1) {
-                    const unsigned par = (A.parents >> (3 * (o & 7))) & 7u;       // SPEC §4.2: target of option o
-                    const bool succ = (par == 0) ? goal : ((inA >> par) & 1u);
-                    const bool fail = !succ && !((inA >> (o & 31)) & 1u);
-                    const bool otime = osteps + 1 >= A.max_opt;
-                    const bool term = (dn != 0) || succ || fail || otime;
-                    ro = rew + (succ ? A.r_succ : 0.0f);
-                    co = term ? 0.0f : A.gamma;
-                    keep = !term;
-                }
-                // smallest k with in_k(s_next) and s_next outside k's target region
-                unsigned tgtB = 0;                    // bit k: s_next already lies in option k's target region
-#pragma unroll
-                for (int k = 1; k < MAX_VF; ++k) {
-                    const unsigned par = (A.parents >> (3 * k)) & 7u;
-                    if (par != 0 && ((inB >> par) & 1u)) tgtB |= 1u << k;
-                }
-                const unsigned sel = inB & ~tgtB & A.enabled;         // a gestating option is never selected
-                const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
-                s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o; s_on[i] = (uint8_t)on;
-                s_gs[i] = (uint8_t)inS; s_ia[i] = (uint8_t)((inA & 0x3Eu) | (goal ? 1u : 0u));
-                {   // bit masks of the VFs with items / update items here: OR over the wave's lanes first (7 ballots), then
-                    // one LDS atomic per wave instead of one per env on a single word
-                    const unsigned pm = (1u << (o & 31)) | (1u << (on & 31)) | inS, um = (1u << (o & 31)) | inS;
-                    unsigned pw = 0, uw = 0;
-#pragma unroll
-                    for (int k = 0; k < MAX_VF + 1; ++k) {
-                        if (__ballot((pm >> k) & 1u)) pw |= 1u << k;
-                        if (__ballot((um >> k) & 1u)) uw |= 1u << k;
-                    }
-                    if (lane == __builtin_ctzll(__ballot(true))) {
-                        atomicOr(reinterpret_cast<unsigned *>(&s_misc[31]), pw);
-                        atomicOr(reinterpret_cast<unsigned *>(&s_misc[30]), uw);
-                    }
-                }
-                if (inS && A.gest_succ) {                             // SPEC §4.4: gestation successes (integer counts: order-free)
-#pragma unroll
-                    for (int k = 1; k < MAX_VF; ++k) {
-                        const unsigned par = (A.parents >> (3 * k)) & 7u;
-                        if (((inS >> k) & 1u) && ((par == 0) ? goal : (bool)((inA >> par) & 1u))) atomicAdd(&A.gest_succ[k], 1);
-                    }
-                }
-                s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
-                // results -> staging record at this env's POSITION (full-line stores); commit_row scatters them
-                // to the caller's arrays in env order. (Direct 4-byte stores from here dirtied every 64-byte line
-                // from ~6 workgroups on different XCDs: ≈ 9 us of partial-line writes per step.)
-                {
-                    const int osn = keep ? osteps + 1 : 0, epn = dn ? 0 : eps1;
-                    float4 *orec = A.outrec + (size_t)(e0 + i) * 4;
-                    orec[0] = make_float4(nx, ny, nvx, nvy);
-                    orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
-                                          __int_as_float(osn), __int_as_float(epn));
-                }
-                SCG_STAMP(19);                                        // P: bookkeeping, option logic, result line
-                if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
-                    const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
-                    A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
-                }
-                if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
-                if (A.hist_next) atomicAdd(&A.hist_next[(e >> 8) * 8 + on], 1);   // next step's counting sort
-            } else {
-                s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
-            }
-        } else if (valid) {
-            if (MODE == MODE_TRANS) {
-                s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
-                s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
-                s_s[4 * BLOCK_ENVS + i] = A.xn[e]; s_s[5 * BLOCK_ENVS + i] = A.yn[e];
-                s_s[6 * BLOCK_ENVS + i] = A.vxn[e]; s_s[7 * BLOCK_ENVS + i] = A.vyn[e];
-                s_a[i] = A.action[e]; s_ot[i] = (uint8_t)A.k_lo; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
-                const float r = A.reward[e], c = A.cont_in[e];
-                s_r0[i] = r; s_c0[i] = c; s_ro[i] = r; s_co[i] = c;
-            } else {
-                s_s[4 * BLOCK_ENVS + i] = A.x[e]; s_s[5 * BLOCK_ENVS + i] = A.y[e];
-                s_s[6 * BLOCK_ENVS + i] = A.vx[e]; s_s[7 * BLOCK_ENVS + i] = A.vy[e];
-                s_a[i] = 0; s_ot[i] = 255; s_on[i] = (uint8_t)A.k_lo; s_gs[i] = 0; s_ia[i] = 0;
-                s_r0[i] = 0.0f; s_c0[i] = 0.0f; s_ro[i] = 0.0f; s_co[i] = 0.0f;
-            }
-        } else {
-            s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
-        }
-    } else if (MODE == MODE_FUSED && wave < P_POOL) {   // no envs of its own: takes its share of the physics' pair groups
-        lds_await(&s_misc[24], P_WAVES);
-        int gsum[P_WAVES + 1];
-        gsum[0] = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[22 + w2];
-        for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
-            int owner = 0;
-#pragma unroll
-            for (int w2 = 1; w2 < P_WAVES; ++w2) owner += q >= gsum[w2] ? 1 : 0;
-            pinball_wave_group(s_edges, A.ms, s_pitems + owner * PITEMS + 64 * (q - (owner ? gsum[1] : 0)),
-                               s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
-        }
-        lds_arrive(&s_misc[25], 1);
-    } else if (helpers && wave >= HELPER0) {
-        const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index (256 threads, 4 waves)
-        stage_w(A.W, ht, THREADS - HELPER0 * 64);
-        lds_await(&s_misc[29], nb);                                                    // the P waves have published s and a
-        if (ht < nb) {                                                                 // Z_d^1 of the entry states
-            const float sv2 = fmaf(s_s[2 * BLOCK_ENVS + ht], 0.25f, 0.5f), sv3 = fmaf(s_s[3 * BLOCK_ENVS + ht], 0.25f, 0.5f);
-            const float2 za = sincospi_cs(s_s[ht]), zb = sincospi_cs(s_s[BLOCK_ENVS + ht]), zc = sincospi_cs(sv2), zd = sincospi_cs(sv3);
-            float4 *dst = reinterpret_cast<float4 *>(s_z1 + (ht * 2 + 0) * 4);
-            dst[0] = make_float4(za.x, za.y, zb.x, zb.y);
-            dst[1] = make_float4(zc.x, zc.y, zd.x, zd.y);
-        }
-        // the root's update list (every env, one run per action, block order inside a run): each helper wave derives the
-        // run geometry itself from two rounds of ballots; helper wave 0 writes the list
-        int rl[NACT], ro[NACT];
-        {
-            uint64_t m0[NACT], m1[NACT];
-            const int at0 = lane < nb ? s_a[lane] : -1, at1 = 64 + lane < nb ? s_a[64 + lane] : -1;
-            int off = 0;
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-                m0[a] = __ballot(at0 == a); m1[a] = __ballot(at1 == a);
-                rl[a] = __popcll(m0[a]) + __popcll(m1[a]); ro[a] = off; off += rl[a];
-            }
-            if (hw == 0) {
-                const uint64_t below = (1ull << lane) - 1ull;
-#pragma unroll
-                for (int a = 0; a < NACT; ++a) {
-                    if (at0 == a) s_ulist[ro[a] + __popcll(m0[a] & below)] = (uint16_t)lane;
-                    if (at1 == a) s_ulist[ro[a] + __popcll(m0[a]) + __popcll(m1[a] & below)] = (uint16_t)(64 + lane);
-                }
-            }
-        }
-        lds_arrive(&s_misc[28], 1);
-        lds_await(&s_misc[28], WAVES - HELPER0);                               // W_0, Z(s) and the list are complete
-        run_u1(hw, WAVES - HELPER0, rl, ro, 0);
-#ifdef SCG_STAMPS
-        if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
-#endif
-    }
-    // From here on waves 0..1 run at priority 1 and the others at 0: waves 0 and 1 build every pass's lists (the other
-    // six wait for them at the next barrier). (Round 2 had waves 0..3 at 1; 0..1 measured +0.3..0.45 % in round 3.) Measured against no priority:
-    // +2.0 % env-steps/s; the same for waves 0..1 only; 0 % for waves 4..7, odd waves or one whole workgroup of the CU.
-    if (helpers) { if (wave < P_WAVES) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    block_lds_sync();
-
-    SCG_STAMP(0);   // phase P
-    // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s and s_next
-    // one sincospi per thread and round: thread -> (env i, state sg, variable d)
-    for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {
-        const int i = u & (BLOCK_ENVS - 1), d = (u / BLOCK_ENVS) & 3, sg = u / (4 * BLOCK_ENVS);
-        if (i < nb && (MODE != MODE_QVAL || sg == 1) && !(helpers && sg == 0)) {
-            const float sv = s_s[(4 * sg + d) * BLOCK_ENVS + i];
-            s_z1[(i * 2 + sg) * 4 + d] = sincospi_cs(d < 2 ? sv : fmaf(sv, 0.25f, 0.5f));
-        }
-    }
-
-    // ------------------------------------------------------------------ phase TD (SPEC §3.1, §5) on the matrix pipe
-    const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[31]) : ~0u;
-    // value functions that only have envs ENTERING them here (evaluation-only: no update item, a handful of items — 1.6
-    // such VFs with 3.5 items each per workgroup on the bench workload) skip the pass machinery: see the tail of the kernel
-    const unsigned eval_only = (MODE == MODE_FUSED && A.learn) ? (present & ~(unsigned)__builtin_amdgcn_readfirstlane(s_misc[30])) : 0u;
-    for (int k = A.k_lo; k <= A.k_hi; ++k) {
-        if (!((present >> k) & 1u) || ((eval_only >> k) & 1u)) {   // nobody here runs or enters option k: skip the pass outright
-            if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = 0;
-            continue;
-        }
-        block_lds_sync();
-        SCG_STAMP(k == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
-        // ---- the workgroup's item lists for VF k (SPEC §5), built by ballot + popcount over the 128 envs:
-        //   eval list   : envs that need Q_k(s_next, .) (bootstrap target and/or next action), block order
-        //   update lists: envs that update VF k, one run per action a_t, block order inside a run
-        bool ev = false, up = false;
-        int at = -1;
-        if (tid < nb) {
-            const int ot = s_ot[tid], on = s_on[tid];
-            const bool own = (MODE == MODE_FUSED && k == 0) || ot == k;
-            const bool gst = MODE == MODE_FUSED && !own && ((s_gs[tid] >> k) & 1);       // SPEC §4.4 off-policy item
-            up = (MODE != MODE_QVAL) && A.learn && (own || gst);
-            float rk = s_r0[tid], cont = s_c0[tid];
-            if (MODE == MODE_FUSED && k != 0) {
-                if (ot == k) { rk = s_ro[tid]; cont = s_co[tid]; }
-                else {                                    // as if the env ran option k: no time-out, no selection
-                    const unsigned ia = s_ia[tid], par = (A.parents >> (3 * k)) & 7u;
-                    const bool succ = (par == 0) ? (ia & 1u) : ((ia >> par) & 1u);
-                    const bool fail = !succ && !((ia >> k) & 1u);
-                    rk = rk + (succ ? A.r_succ : 0.0f);
-                    cont = (cont == 0.0f || succ || fail) ? 0.0f : A.gamma;
-                }
-            }
-            s_rk[tid] = rk; s_ck[tid] = cont;
-            ev = (on == k) || (up && cont > 0.0f);
-            at = s_a[tid];
-        }
-        uint64_t mb[1 + NACT];
-        if (wave < LIST_WAVES) {
-            mb[0] = __ballot(ev);
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) mb[1 + a] = __ballot(up && at == a);
-            if (lane < 1 + NACT) {
-                const uint64_t mine = lane == 0 ? mb[0] : lane == 1 ? mb[1] : lane == 2 ? mb[2] : lane == 3 ? mb[3]
-                                                        : lane == 4 ? mb[4] : mb[5];
-                s_misc[wave * 8 + lane] = __popcll(mine);
-            }
-        }
-        SCG_STAMP(23);                                       // (diagnostic) flags + ballots
-        const float *Wk = A.W + (MODE == MODE_QVAL ? 0 : (size_t)k * NACT * NF);
-        if (!(helpers && k == 0)) stage_w(Wk, tid, THREADS);   // (the helper waves staged W_0 under phase P)
-        SCG_STAMP(24);                                       // (diagnostic) W staging
-        block_lds_sync();
-        SCG_STAMP(25);                                       // (diagnostic) wait at the barrier behind the staging
-        int n_ev = 0, run_len[NACT], run_off[NACT];
-        {
-            int se = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < LIST_WAVES; ++w2) se += s_misc[w2 * 8];
-            n_ev = __builtin_amdgcn_readfirstlane(se);
-            int off = 0;
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {      // wave-uniform: keep them in SGPRs
-                int sr = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < LIST_WAVES; ++w2) sr += s_misc[w2 * 8 + 1 + a];
-                run_len[a] = __builtin_amdgcn_readfirstlane(sr);
-                run_off[a] = off;
-                off += run_len[a];
-            }
-        }
-        const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
-        if (wave < LIST_WAVES) {
-            const uint64_t below = (1ull << lane) - 1ull;
-            if (ev) {
-                int off = 0;
-                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[w2 * 8];
-                s_elist[off + __popcll(mb[0] & below)] = (uint16_t)tid;
-            }
-            if (up) {
-                int off = 0;
-                const uint64_t mine = at == 0 ? mb[1] : at == 1 ? mb[2] : at == 2 ? mb[3] : at == 3 ? mb[4] : mb[5];
-                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[w2 * 8 + 1 + at];
-                const int ro = at == 0 ? run_off[0] : at == 1 ? run_off[1] : at == 2 ? run_off[2] : at == 3 ? run_off[3] : run_off[4];
-                s_ulist[ro + off + __popcll(mine & below)] = (uint16_t)tid;
-            }
-        }
-        block_lds_sync();
-        if (tid == 0 && A.cnts) A.cnts[(size_t)b * A.n_vf + k] = nupd;
-        SCG_STAMP(k == 0 ? 1 : 8);    // phase Z (first pass only) + list build + W staging
-        if (n_ev + nupd == 0) continue;
-
-        // column blocks of this pass: nqe of the eval list, then per action run ceil(run_len / 8) of the update list;
-        // block index i goes to wave i & 7
-        const int nqe = (n_ev + 7) >> 3;
-        if (wave < nqe) {
-            // ---- E: Q_k(s_next, .) of the eval list, one 8-item column block per wave-iteration (SPEC §3.1)
-            for (int cb = wave; cb < nqe; cb += WAVES) {
-                build_block(s_elist, 8 * cb, min(8, n_ev - 8 * cb), 1);
-                wave_lds_sync();
-                float B[9];
-#pragma unroll
-                for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-                f4v acc[12];
-#pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const f4v a0 = w4[(t * 2) * 64], a1 = w4[(t * 2 + 1) * 64];
-                    const float a8 = w8[t * 64];
-                    f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
-                }
-                // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
-                float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const int Ct = (16 * t) % 36, At = (16 * t) / 36;
-                    if (Ct + 12 < 36) {                          // the tile's 16 rows belong to one action
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + Ct);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) q[At] = fmaf(acc[t][v], ab4[v], q[At]);
-                    } else {                                     // row groups g >= (36 - Ct) / 4 belong to the next action
-                        const bool wrap = 4 * g >= 36 - Ct;
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + (wrap ? Ct - 36 : Ct));
-                        float xq = wrap ? q[At + 1] : q[At];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) xq = fmaf(acc[t][v], ab4[v], xq);
-                        q[At] = wrap ? q[At] : xq;
-                        q[At + 1] = wrap ? xq : q[At + 1];
-                    }
-                }
-                float qo[NACT] = {q[0], q[1], q[2], q[3], q[4]};
-                item_tree_sum<NACT>(qo);
-                if (out_lane && 8 * cb + ocol_item < n_ev) {
-                    const int il = s_elist[8 * cb + ocol_item];
-                    if (s_on[il] == k) {
-                        if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
-                            float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
-                            orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
-                            orec[3].x = qo[4];
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + s_env[il]], qo[a]);
-                        }
-                    }
-                    float mx = qo[0];
-#pragma unroll
-                    for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
-                    s_maxq[il] = mx;
-                }
-                wave_lds_sync();
-            }
-        }
-        SCG_STAMP(k == 0 ? 3 : 10);   // E (wave 0's share)
-        // ---- U1 (the root's ran under phase P on the helper waves)
-        if (MODE != MODE_QVAL && nupd > 0 && !(helpers && k == 0)) run_u1(wave, WAVES, run_len, run_off, nqe);   // dealt on behind E's blocks
-        if (MODE == MODE_QVAL || nupd == 0) continue;
-        SCG_STAMP(k == 0 ? 4 : 11);   // U1 (wave 0's share)
-        block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
-        SCG_STAMP(k == 0 ? 7 : 14);   // wait for the other waves
-
-        // ---- U2: the block partial (SPEC §5). Padded slots: every action run is padded with null items to a multiple of
-        // 4, run a occupying slots [off4[a], off4[a] + len4[a]). Chunks of U2_CH = 72 slots (144 K-steps, kap = 2 slot + part):
-        //   build  PT[c12][kap] = delta * ABsel, CDT[c34][kap] = CD  (null items: +0); wave w owns slots 9 w .. 9 w + 8
-        //   MFMA   G[a] += PT x CDT^T, groups of 4 items: one MFMA over their real parts, one over the imaginary parts;
-        //          the 9 output tiles of action a are dealt to the 8 waves (tile q -> wave (q + a) & 7, so wave a holds two),
-        //          accumulators stay in registers for the whole pass and go straight to the block's slab
-        int off4[NACT + 1];
-        off4[0] = 0;
-#pragma unroll
-        for (int a = 0; a < NACT; ++a) off4[a + 1] = off4[a] + ((run_len[a] + 3) & ~3);
-        int wave_u = wave;
-        asm volatile("" : "+s"(wave_u));                    // keeps the per-(wave, action) tile geometry inside the pass
-        f4v accU[NACT][2];
-#pragma unroll
-        for (int a = 0; a < NACT; ++a) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) accU[a][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        float *ptab = s_R, *ctab = s_R + 36 * US;
-        const int bi9 = lane % 9, cp9 = lane / 9;           // builder lanes of a chunk: (slot 9 wave + bi9, second index cp9 < 6)
-        for (int ch0 = 0; ch0 < off4[NACT]; ch0 += U2_CH) {
-            if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
-            SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
-            {
-                const int slot = 9 * wave + bi9, ps = ch0 + slot;
-                const int cp = cp9;                                           // (shadows the 8-item builders' cp in this scope)
-                if (cp < 6 && ps < off4[NACT]) {
-                    int a_ = 0;
-#pragma unroll
-                    for (int a = 1; a < NACT; ++a) a_ += ps >= off4[a] ? 1 : 0;
-                    const int o4 = a_ == 0 ? off4[0] : a_ == 1 ? off4[1] : a_ == 2 ? off4[2] : a_ == 3 ? off4[3] : off4[4];
-                    const int rl = a_ == 0 ? run_len[0] : a_ == 1 ? run_len[1] : a_ == 2 ? run_len[2] : a_ == 3 ? run_len[3] : run_len[4];
-                    const int ro = a_ == 0 ? run_off[0] : a_ == 1 ? run_off[1] : a_ == 2 ? run_off[2] : a_ == 3 ? run_off[3] : run_off[4];
-                    const int j = ps - o4;
-                    float *pd = ptab + cp * US + 2 * slot, *cdst = ctab + cp * US + 2 * slot;
-                    if (j < rl) {
-                        const int li = ro + j, il = s_ulist[li];
-                        const float rr = s_rk[il], cont = s_ck[il];
-                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
-                        const float d = target - s_qsa[li];
-                        float2 ab[6], cd[6];
-                        item_entries(s_z1 + (il * 2 + 0) * 4, cp, ab, cd);
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            *reinterpret_cast<float2 *>(pd + 6 * c * US) = make_float2(d * ab[c].x, d * (-ab[c].y));
-                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(cd[c].x, cd[c].y);
-                        }
-                    } else {                                     // null item padding a run to a multiple of 4
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            *reinterpret_cast<float2 *>(pd + 6 * c * US) = make_float2(0.0f, 0.0f);
-                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(0.0f, 0.0f);
-                        }
-                    }
-                }
-            }
-            SCG_STAMP(21);                                       // (diagnostic) U2: build
-            block_lds_sync();                                    // operands visible
-            SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
-            auto run_u2 = [&](auto aa_c) {
-                constexpr int AA = decltype(aa_c)::value;
-                const int lo = max(off4[AA], ch0), hi = min(off4[AA + 1], ch0 + U2_CH);   // the run's slots in this chunk
-                if (lo >= hi) return;
-                const bool two = wave_u == AA;                   // this wave's tiles: (wave - AA) & 7, and tile 8 on wave AA
-                const float *pa[2], *pb[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int q = s == 0 ? ((wave_u - AA) & 7) : 8;
-                    const int mi = (q * 11) >> 5, ni = q - 3 * mi;             // q / 3, q % 3
-                    pa[s] = ptab + min(16 * mi + n16, 35) * US + 2 * g + 2 * (lo - ch0);
-                    pb[s] = ctab + min(16 * ni + n16, 35) * US + 2 * g + 2 * (lo - ch0);
-                }
-                const int ngrp = (hi - lo) >> 2;
-                if (two) {
-                    for (int gi = 0; gi < ngrp; ++gi) {
-                        float2 a2[2], b2[2];
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) { a2[s] = *reinterpret_cast<const float2 *>(pa[s] + 8 * gi); b2[s] = *reinterpret_cast<const float2 *>(pb[s] + 8 * gi); }
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2[s].x, a2[s].x, accU[AA][s], 0, 0, 0);
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) accU[AA][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2[s].y, a2[s].y, accU[AA][s], 0, 0, 0);
-                    }
-                } else {
-                    for (int gi = 0; gi < ngrp; ++gi) {
-                        const float2 a2 = *reinterpret_cast<const float2 *>(pa[0] + 8 * gi), b2 = *reinterpret_cast<const float2 *>(pb[0] + 8 * gi);
-                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.x, a2.x, accU[AA][0], 0, 0, 0);
-                        accU[AA][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.y, a2.y, accU[AA][0], 0, 0, 0);
-                    }
-                }
-            };
-            run_u2(std::integral_constant<int, 0>{}); run_u2(std::integral_constant<int, 1>{});
-            run_u2(std::integral_constant<int, 2>{}); run_u2(std::integral_constant<int, 3>{});
-            run_u2(std::integral_constant<int, 4>{});
-        }
-        SCG_STAMP(k == 0 ? 6 : 13);   // U2
-        // the block partial P_b,k straight from the accumulators (zeros for an empty run). The tiles were accumulated
-        // TRANSPOSED (A operand = CDT rows, B operand = PT rows; fma(a, b, c) = fma(b, a, c)), so register v of lane (n16, g)
-        // of tile (mi, ni) is G[a][c12 = 16 mi + n16][c34 = 16 ni + 4 g + v]: four consecutive floats per lane, one 16-byte
-        // store instead of four 4-byte ones (the epilogue is store-issue-bound)
-        {
-            float *slab_lane = A.slabs + ((size_t)b * A.n_vf + k) * NACT * NF + n16 * 36 + 4 * g;
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int q = s == 0 ? ((wave_u - a) & 7) : 8;
-                    if (s == 0 || wave_u == a) {
-                        const int mi = (q * 11) >> 5, ni = q - 3 * mi;         // wave-uniform
-                        const bool okl = (mi < 2 || n16 < 4) && (ni < 2 || g == 0);
-                        if (okl) store_wt(slab_lane + a * NF + (16 * mi) * 36 + 16 * ni, accU[a][s]);
-                    }
-                }
-            }
-        }
-        SCG_STAMP(15);                // slab stores issued
-    }
-    // ------------------------------------------------------------------ evaluation-only value functions, on the vector pipe
-    // Q_k(s_next, .) of the few envs entering an option nobody in this workgroup runs. The (value function, env) pairs are
-    // enumerated in a fixed order by every wave and dealt round-robin; a wave evaluates its pair alone, with W_k read
-    // straight from global memory (one 36-float row per lane and round) — no staging, no lists, no workgroup barrier. The
-    // arithmetic is SPEC §3.1 operation for operation (the MFMA is the same fmaf chain), so the result is bit-identical to
-    // what a pass would have produced; a full pass for 3.5 items cost ~16k cycles, 1.6 times per workgroup.
-    if (MODE == MODE_FUSED && eval_only && A.k_hi >= 0) {
-        block_lds_sync();                                   // region R is free again
-        SCG_STAMP(26);
-        float2 *t_ab = reinterpret_cast<float2 *>(cdk), *t_cd = t_ab + 36, *t_T = t_cd + 36;      // this wave's table area: 36 + 36 + 180 float2
-        int pair = 0;
-        for (int k = 1; k < A.n_vf; ++k) {
-            if (!((eval_only >> k) & 1u)) continue;
-            const float *Wk = A.W + (size_t)k * NACT * NF;
-            for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
-                const int ii = 64 * h + lane;
-                uint64_t m = __ballot(ii < nb && s_on[ii] == k);
-                while (m) {
-                    const int il = 64 * h + (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    if ((pair++ & (WAVES - 1)) != wave) continue;
-                    // tables of s_next: lane c < 36 owns AB[c] and CD[c] (c = 6 hi + lo)
-                    if (lane < 36) {
-                        const float4 *zp = reinterpret_cast<const float4 *>(s_z1 + (il * 2 + 1) * 4);
-                        const float4 za = zp[0], zc = zp[1];
-                        const int hi = (lane * 43) >> 8, lo = lane - 6 * hi;                  // lane / 6, lane % 6 for lane < 36
-                        float2 ab = zpow_sel(make_float2(za.z, za.w), lo), cd = zpow_sel(make_float2(zc.z, zc.w), lo);
-#pragma unroll
-                        for (int c = 1; c < 6; ++c) {                                         // row hi: hi chained products
-                            const float2 abn = cmul(ab, make_float2(za.x, za.y)), cdn = cmul(cd, make_float2(zc.x, zc.y));
-                            if (c <= hi) { ab = abn; cd = cdn; }
-                        }
-                        t_ab[lane] = make_float2(ab.x, -ab.y);
-                        t_cd[lane] = cd;
-                    }
-                    wave_lds_sync();
-                    // T[row][re | im], row = 36 a + c12: the fmaf chain over c34 = 9 g + kb (kb outer, g inner)
-#pragma unroll 1
-                    for (int r0 = 0; r0 < 192; r0 += 64) {
-                        const int row = r0 + lane;
-                        if (row < 180) {
-                            const float4 *wr = reinterpret_cast<const float4 *>(Wk + row * 36);
-                            float wv[36];
-#pragma unroll
-                            for (int q4 = 0; q4 < 9; ++q4) {
-                                const float4 w = wr[q4];
-                                wv[4 * q4] = w.x; wv[4 * q4 + 1] = w.y; wv[4 * q4 + 2] = w.z; wv[4 * q4 + 3] = w.w;
-                            }
-                            float tre = 0.0f, tim = 0.0f;
-#pragma unroll
-                            for (int kb = 0; kb < 9; ++kb) {
-#pragma unroll
-                                for (int gg = 0; gg < 4; ++gg) {
-                                    const float2 cdv = t_cd[9 * gg + kb];
-                                    tre = fmaf(wv[9 * gg + kb], cdv.x, tre);
-                                    tim = fmaf(wv[9 * gg + kb], cdv.y, tim);
-                                }
-                            }
-                            t_T[row] = make_float2(tre, tim);
-                        }
-                    }
-                    wave_lds_sync();
-                    // q[a][g][part]: lane = 8 a + 2 g + part chains over its nine c12 in increasing order, then the tree
-                    float qv = 0.0f;
-                    {
-                        const int a = min(lane >> 3, NACT - 1), gq = (lane >> 1) & 3, part = lane & 1;
-                        // rows 36 a + c12 of group gq: c12 = 4 i + v with ((36 a) / 4 + i) % 4 == gq  ->  i = (gq - 9 a) & 3, + 4, + 8
-                        const int i0 = (gq - 9 * a) & 3;
-#pragma unroll
-                        for (int ii3 = 0; ii3 < 3; ++ii3) {
-                            const int i = i0 + 4 * ii3;                                  // i = 0..8: quad of rows 4 i .. 4 i + 3
-                            if (i < 9) {
-#pragma unroll
-                                for (int v = 0; v < 4; ++v) {
-                                    const float2 tv = t_T[36 * a + 4 * i + v], av = t_ab[4 * i + v];
-                                    qv = fmaf(part ? tv.y : tv.x, part ? av.y : av.x, qv);
-                                }
-                            }
-                        }
-                    }
-                    qv = qv + __shfl_xor(qv, 1, 64);                      // u_g = q_re + q_im
-                    qv = qv + __shfl_xor(qv, 2, 64);                      // u_0 + u_1 | u_2 + u_3
-                    qv = qv + __shfl_xor(qv, 4, 64);                      // (u_0 + u_1) + (u_2 + u_3)
-                    if (lane < 8 * NACT && (lane & 7) == 0)               // into the env's result line (orec[2].xyzw, orec[3].x)
-                        reinterpret_cast<float *>(A.outrec + (size_t)(e0 + il) * 4)[8 + (lane >> 3)] = qv;
-                    wave_lds_sync();
-                }
-            }
-        }
-        SCG_STAMP(27);
-    }
-#ifdef SCG_STAMPS
-    if (MODE == MODE_FUSED && A.stamps) {
-        __syncthreads();
-        if (tid < 32) A.stamps[(size_t)blockIdx.x * 32 + tid] += s_stamp[tid];
-    }
-#endif
-}
+#include "scg_step_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // slabs -> G (SPEC §5 two-level block order), n_k, optional apply; the next step's env order rides along
@@ -1708,7 +849,8 @@ __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8
                 // cooperative one: MI355X_MICROARCH.md, residency) promises that only on an otherwise idle card: another
                 // stream or process may hold CUs. A late partner is waited for on the 100 MHz wall clock — seconds,
                 // not a spin count — and a partner that never shows up ABORTS the fit: weights left as they were,
-                // SCG_ASYNC_FIT_TIMEOUT raised in the ctx's host-visible status word (scg_async_status).
+                // SCG_ASYNC_FIT_TIMEOUT raised in the ctx's host-visible status word (scg_async_status) by the
+                // problem's workgroup 0, the only one that writes the row.
                 unsigned long long t0 = 0;
                 int spins = 0;
                 while (((v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (tag >> 32)) {
@@ -1734,8 +876,11 @@ __global__ __launch_bounds__(FIT_T) void fit_kernel(const float *xy, const uint8
         if (s_abort) break;
     }
     __syncthreads();
-    if (s_abort) {                                        // no silent NaN row: w keeps its old value, the host is told
-        if (tid == 0 && async_word)
+    if (s_abort) {                                        // no silent NaN row: w keeps its old value, the host is told.
+        // Workgroup 0 of the problem alone decides: it is the one that writes the row, so "status bit raised" and "row left
+        // untouched" are the same event. A partner that gives up merely exits (workgroup 0 then either holds everything it
+        // needs — the partner had published its last partial — and finishes exactly, or runs out of patience itself).
+        if (j == 0 && tid == 0 && async_word)
             __hip_atomic_fetch_or(async_word, SCG_ASYNC_FIT_TIMEOUT | (0x100u << (q & 15)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
@@ -1813,7 +958,11 @@ static int fail(scg_ctx *ctx, int code, const char *msg) {
 static int decode_async(uint32_t word, char *buf, size_t n) {
     if (word == 0) { if (buf && n) buf[0] = 0; return SCG_OK; }
     if (buf && n) {
-        if (word & SCG_ASYNC_FIT_TIMEOUT)
+        if (word & SCG_ASYNC_STEP_HANDOFF)
+            snprintf(buf, n, "an earlier scg_step gave up inside a workgroup: a bounded hand-off poll between its wavefront subsets ran "
+                     "out (a logic error or a hung wavefront); the block's partial gradients were dropped and the step's outputs for "
+                     "its envs are unspecified — restore the state. scg_clear_async_error() re-arms the context");
+        else if (word & SCG_ASYNC_FIT_TIMEOUT)
             snprintf(buf, n, "an earlier scg_fit_initiation gave up (problem mask 0x%x): its workgroups did not become "
                      "co-resident within the fit timeout (card shared with other work?); the affected classifier rows were "
                      "left unchanged. scg_clear_async_error() re-arms the context", (word >> 8) & 0xffffu);
@@ -2062,6 +1211,7 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.ring_x = c->ring_x; A.ring_y = c->ring_y; A.events = c->events; A.ev_len = c->ev_len;
     A.ring_mask = c->ring_len > 0 ? c->ring_len - 1 : 0;
     A.stamps = c->d_stamps;
+    A.async_word = c->d_async;
 }
 
 // The reduce launch; for the fused step (`st` given) its extra workgroups also commit the step's per-position
@@ -2107,6 +1257,22 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
         return fail(c, SCG_ERR_INVALID, "scg_step: null array argument");
     SCG_CHECK_ASYNC(c);
     SCG_ON_DEVICE(c, "scg_step");
+    if (c->arm_bits) {
+        // An announced trigger (scg_arm_collect) makes this step's commit rows read the caller's prev_in / count buffers:
+        // refuse to launch if they are no longer device allocations (freed since the announcement) instead of faulting
+        // the GPU. Two host-side attribute queries per step, only while a trigger is armed.
+        const void *ptrs[2] = {c->arm_count, c->arm_prev};
+        for (const void *p : ptrs) {
+            if (!p) continue;
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeDevice) {
+                (void)hipGetLastError();
+                c->arm_bits = 0; c->arm_rows_ready = false;
+                return fail(c, SCG_ERR_STATE, "scg_step: the buffers announced with scg_arm_collect are no longer device memory "
+                                              "(freed before scg_arm_collect(0)?); the trigger has been disarmed");
+            }
+        }
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     StepArgs A;
     fill_common(c, A);

@@ -1,0 +1,978 @@
+// scg_step_kernel.hpp — td_kernel: the step-batch kernel of SPEC §1.3–§5 (included by scg_kernels.hip).
+//
+// Round 4: ONE 16-wavefront workgroup per CU owns a block of 256 consecutive positions of the option-sorted env order
+// (SPEC §5, B = 256) and all 160 KB of the CU's LDS. The root value function and the block's option — the option whose
+// envs are the position PREFIX of the block, which is what the chunked env order produces — are staged TOGETHER
+// (W_0 and W_k, 54 KB) and run as ONE merged pass: every table of Fourier factors is built once per state and
+// serves both value functions:
+//   phase P  waves 0..3 one lane per env (act, Pinball physics, bookkeeping, option logic), the physics' (env, edge) pair
+//            groups pooled over waves 0..7; MEANWHILE waves 8..15 stage W_0 and W_k, take Z_d^1 of the entry states,
+//            build the root's update list and run U1 of BOTH value functions (Q_0(s, a_t) and Q_k(s, a_t) from one set of
+//            tables per 8-item column block)
+//   phase Z  Z_d^1 of s_next
+//   E        per 8-env position group one table build of s_next, then 108 MFMAs per value function that needs the group
+//            (T = W (180 x 36, A operands streamed from LDS) x [Re CD | Im CD]); the few envs ENTERING the block's
+//            option from outside the prefix are compacted into extra column blocks
+//   U2       chunks of 144 padded slots of the root's update list (sorted by action, position): one build per slot gives
+//            CDT (shared), PT_0 = delta_0 ABsel and, for the prefix slots, PT_k = delta_k ABsel; the 90 output tiles
+//            (2 value functions x 5 actions x 9) are dealt to the 16 waves, accumulators stay in registers for the pass
+//   Because an option's items are a prefix of every action run of the root's list, its groups of four are the root's
+//   groups of four: the accumulation order of SPEC §5 is reproduced exactly (null items masked to +0 on both operands).
+// Value functions with update items that are NOT that prefix (gestating options, a second option in the padded env
+// order) take a single-VF pass of their own afterwards (compacted lists, as in rounds 2-3); value functions that only
+// have envs entering them are evaluated on the vector pipe in the tail. MODE_TRANS / MODE_QVAL are single passes.
+// Every sum has the pinned order of SPEC §3.1 / §5 (no atomics on data): the CPU oracle reproduces every bit.
+#pragma once
+
+constexpr int P_WAVES = BLOCK_ENVS / 64;      // phase P: one lane per env on full waves
+constexpr int HELPER0 = WAVES / 2;            // waves HELPER0.. work under phase P (learning steps)
+constexpr int N_HELP = WAVES - HELPER0;
+constexpr int P_POOL = HELPER0;               // waves 0..P_POOL-1 share the physics' (env, edge) pair groups
+static_assert((N_HELP & (N_HELP - 1)) == 0 && (WAVES & (WAVES - 1)) == 0, "column blocks are dealt with a power-of-two mask");
+// LDS map of the step kernel (bytes): one workgroup per CU, the whole 160 KB.
+constexpr int OFF_RC = 0;                                      // float r0,c0,ro,co (per env), rk,ck (per env, single passes) [B]
+constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia, ev [B]
+constexpr int OFF_Z1 = OFF_INT + 6 * BLOCK_ENVS;               // float2 z1[B][2][4]: Z_d^1 of s and s_next
+// region R, used by one phase at a time:
+//   P, Z  : s[4][B], sn[4][B] (the envs' states), the edge table [256][8] and the pair lists, inside the table area of waves 0..7
+//   E, U1 : W_A | W_B staged in A-operand order (12 row tiles x 9 k-blocks x 64 lanes each) + per wave CDk[36][16] + ABq[16][AS]
+//   U2    : PT_A[36][US], PT_B[36][US], CDT[36][US] (one chunk of U2_CH padded slots = 2 U2_CH K-steps)
+constexpr int W_FLOATS = 12 * 9 * 64;
+constexpr int W_TAIL = 12 * 2 * 64 * 4;                        // k-block 8 of every tile sits behind the two float4 groups
+constexpr int AS = 40;                                         // row stride of ABq (floats): the fold's ds_read_b128 conflict-free
+constexpr int E_TAB_FLOATS = 36 * 16 + 16 * AS;
+constexpr int U2_CH = 9 * WAVES;                               // U2 chunk: padded slots, nine per builder wave (54 of 64 lanes busy)
+constexpr int US = 2 * U2_CH + 4;                              // row stride of the chunk tables (floats): 292 = 36 mod 64, operand reads conflict-free
+constexpr int R_TAB = 2 * W_FLOATS;                            // private tables start behind the staged W_A, W_B
+constexpr int R_S = R_TAB, R_EDGES = R_S + 8 * BLOCK_ENVS, R_PITEMS = R_EDGES + MAX_EDGES * 8;
+constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+constexpr int R_FLOATS = cmax3(R_TAB + WAVES * E_TAB_FLOATS, 3 * 36 * US, R_PITEMS + P_WAVES * PITEMS);
+constexpr int OFF_R = OFF_Z1 + BLOCK_ENVS * 2 * 4 * 8;
+constexpr int OFF_ELIST = OFF_R + R_FLOATS * 4;                // uint16 compacted eval list [2 B] (stragglers / single passes)
+constexpr int OFF_ULIST = OFF_ELIST + 2 * BLOCK_ENVS * 2;      // uint16 update list [B] (5 action runs)
+constexpr int OFF_MAXQ = OFF_ULIST + BLOCK_ENVS * 2;           // float maxq[2][B] (per value function of the pass, per env)
+constexpr int OFF_QSA = OFF_MAXQ + 2 * BLOCK_ENVS * 4;         // float qsa[2][B] (per update-list position)
+constexpr int OFF_EFLAG = OFF_QSA + 2 * BLOCK_ENVS * 4;        // uint8 eflag[B / 8]: per position group, bit v = value function v needs it
+constexpr int OFF_CLF = OFF_EFLAG + 64;                        // float clf[6][8]
+constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[128]
+#ifdef SCG_STAMPS
+constexpr int OFF_STAMP = OFF_MISC + 512;                      // unsigned stamp[32] (diagnostic build)
+constexpr int LDS_BYTES = OFF_STAMP + 128;
+#else
+constexpr int LDS_BYTES = OFF_MISC + 512;
+#endif
+static_assert(BLOCK_ENVS / 8 <= 64, "eflag area");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget: one workgroup per CU");
+static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0 && (R_EDGES * 4) % 16 == 0 && (E_TAB_FLOATS * 4) % 16 == 0, "LDS alignment");
+static_assert(R_PITEMS + P_WAVES * PITEMS <= R_TAB + HELPER0 * E_TAB_FLOATS, "states + edges + the physics pair lists fit the table area of the waves below the helpers");
+// s_misc (ints)
+constexpr int M_CNT = 0;          // [LIST_WAVES][16]: per list wave {compacted-eval count, five action-run counts, five counts of B's share of the runs}
+constexpr int M_GROUPS = 64;      // [P_WAVES] pair groups of each env wave
+constexpr int M_C_PREP = 68;      // hand-off counters: env waves have listed their pair groups,
+constexpr int M_C_POOL = 69;      //   pool waves are through with them,
+constexpr int M_C_HELP = 70;      //   helper waves have staged W / Z(s) / the list,
+constexpr int M_C_PUB = 71;       //   envs whose state and action are published
+constexpr int M_PRESENT = 72;     // bit k: some env here has an item for VF k
+constexpr int M_UPD = 73;         // bit k: ... an UPDATE item
+constexpr int M_FAIL = 74;        // a bounded hand-off poll ran out (reported through the async status word)
+constexpr int M_INTS = 128;
+static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
+
+enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
+
+#ifdef SCG_STAMPS
+#define SCG_STAMP(SEC)                                                                   \
+    do {                                                                                 \
+        if (MODE == MODE_FUSED && A.stamps && tid == 0) {                                \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
+            s_stamp[(SEC)] += (unsigned)(t_ - stamp_prev);                               \
+            stamp_prev = t_;                                                             \
+        }                                                                                \
+    } while (0)
+#else
+#define SCG_STAMP(SEC) do { } while (0)
+#endif
+
+template <int M>
+__device__ __forceinline__ int sel5(const int (&v)[M], int a) {          // v[a], a < 5, without a dynamically indexed array
+    return a == 0 ? v[0] : a == 1 ? v[1] : a == 2 ? v[2] : a == 3 ? v[3] : v[4];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_R = reinterpret_cast<float *>(smem + OFF_R);
+    float *s_s = s_R + R_S;                                             // [8][B]: s then sn   (region R, phases P and Z)
+    float *s_edges = s_R + R_EDGES;                                     // [n_edges][8]        (region R, phase P)
+    uint32_t *s_pitems = reinterpret_cast<uint32_t *>(s_R) + R_PITEMS;  // [P_WAVES][PITEMS] (env, edge) pairs of the physics
+    float *s_r0 = reinterpret_cast<float *>(smem + OFF_RC);
+    float *s_c0 = s_r0 + BLOCK_ENVS, *s_ro = s_c0 + BLOCK_ENVS, *s_co = s_ro + BLOCK_ENVS;
+    float *s_rk = s_co + BLOCK_ENVS, *s_ck = s_rk + BLOCK_ENVS;       // reward / continuation of a single pass's value function
+    uint8_t *s_a = reinterpret_cast<uint8_t *>(smem + OFF_INT);
+    uint8_t *s_ot = s_a + BLOCK_ENVS, *s_on = s_ot + BLOCK_ENVS;
+    uint8_t *s_gs = s_on + BLOCK_ENVS;      // bit k: gestating option k holds s in its initiation set (off-policy item)
+    uint8_t *s_ia = s_gs + BLOCK_ENVS;      // bit 0: goal; bit k: in_k(s')
+    uint8_t *s_ev = s_ia + BLOCK_ENVS;      // bit v: the env needs Q(s_next, .) of value function v of the current pass
+    float2 *s_z1 = reinterpret_cast<float2 *>(smem + OFF_Z1);
+    uint16_t *s_elist = reinterpret_cast<uint16_t *>(smem + OFF_ELIST);
+    uint16_t *s_ulist = reinterpret_cast<uint16_t *>(smem + OFF_ULIST);
+    float *s_maxq = reinterpret_cast<float *>(smem + OFF_MAXQ);
+    float *s_qsa = reinterpret_cast<float *>(smem + OFF_QSA);
+    uint8_t *s_eflag = reinterpret_cast<uint8_t *>(smem + OFF_EFLAG);
+    float *s_W = s_R;                                                   // region W = the head of region R: W_A then W_B
+    float *s_clf = reinterpret_cast<float *>(smem + OFF_CLF);
+    int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int e0 = b * BLOCK_ENVS;
+    const int nb = min(BLOCK_ENVS, A.n - e0);
+    const int N = A.n;
+#ifdef SCG_STAMPS
+    unsigned *s_stamp = reinterpret_cast<unsigned *>(smem + OFF_STAMP);
+    if (tid < 32) s_stamp[tid] = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
+
+    if (tid < M_INTS) s_misc[tid] = (tid == M_PRESENT || tid == M_UPD) ? 1 : 0;
+    if (MODE == MODE_FUSED) {
+        for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
+        if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
+    }
+    block_lds_sync();
+
+    // Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
+    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
+    // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
+    // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
+    // imaginary-part column at 8 h + 4 + i.
+    const int n16 = lane & 15, g = lane >> 4;
+    const int bi = lane & 7, cp = lane >> 3;
+    const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
+    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
+    const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
+    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
+    const float *ab_lane = abq + n16 * AS + 4 * g;
+
+    // private tables of one 8-item column block from the builder lane's item `it` (already clamped by the caller),
+    // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
+    auto build_tables = [&](int it, int sg) {
+        if (cp < 6) {
+            float2 ab[6], cd[6];
+            item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                abq[bcol * AS + 6 * c + cp] = ab[c].x; abq[(bcol + 4) * AS + 6 * c + cp] = -ab[c].y;
+                cdk[(6 * c + cp) * 16 + bcol] = cd[c].x; cdk[(6 * c + cp) * 16 + bcol + 4] = cd[c].y;
+            }
+        }
+    };
+
+    // A operands come from the staged W (value function v of the pass at s_W + v W_FLOATS), per row tile two ds_read_b128
+    // (k-blocks 0..3, 4..7) and one ds_read_b32 (k-block 8)
+    const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane;
+    const float *w8 = s_W + W_TAIL + lane;
+
+    // The pass's update list (s_ulist: items of value function A sorted by action, block order inside a run) and its geometry;
+    // nBa[a] = how many items at the head of run a also update value function B (0 when the pass has none)
+    int run_len[NACT], run_off[NACT], nBa[NACT];
+#pragma unroll
+    for (int a = 0; a < NACT; ++a) { run_len[a] = 0; run_off[a] = 0; nBa[a] = 0; }
+
+    // U1: Q(s, a_t) of the update items, per action run, 8 items per wave-iteration: the contraction of E on the 3 row
+    // tiles that hold action a's rows, for value function A and — while the column block still holds B items — for B on
+    // the SAME tables -> s_qsa[v][list position]. The column blocks of all runs are dealt to `nw` waves.
+    auto run_u1 = [&](int wv, int nw, int base) {
+#pragma unroll 1
+        for (int a = 0; a < NACT; ++a) {
+            const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
+            const int cnt = sel5(run_len, a), cntB = sel5(nBa, a), ro = sel5(run_off, a);
+            const uint16_t *lst = s_ulist + ro;
+            for (int cb = ((wv - base) & (nw - 1)); 8 * cb < cnt; cb += nw) {
+                build_tables(lst[8 * cb + min(bi, cnt - 8 * cb - 1)], 0);
+                wave_lds_sync();
+                float B[9];
+#pragma unroll
+                for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+#pragma unroll 1
+                for (int v = 0; v < 2; ++v) {
+                    const int cv = v ? cntB : cnt;
+                    if (8 * cb >= cv) break;
+                    float qs = 0.0f;
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) {
+                        const int t = t0 + tt;
+                        const f4v a0 = w4[v * (W_FLOATS / 4) + (t * 2) * 64], a1 = w4[v * (W_FLOATS / 4) + (t * 2 + 1) * 64];
+                        const float a8 = w8[v * W_FLOATS + t * 64];
+                        f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
+                        const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
+                        const bool in = r0 >= 0 && r0 < 36;
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * AS + (in ? r0 : 0));
+                        float xq = qs;
+#pragma unroll
+                        for (int vv = 0; vv < 4; ++vv) xq = fmaf(c[vv], ab4[vv], xq);
+                        qs = in ? xq : qs;
+                    }
+                    float qo[1] = {qs};
+                    item_tree_sum<1>(qo);
+                    if (out_lane && 8 * cb + ocol_item < cv) s_qsa[v * BLOCK_ENVS + ro + 8 * cb + ocol_item] = qo[0];
+                }
+                wave_lds_sync();
+            }
+            base += (cnt + 7) >> 3;
+        }
+    };
+    // W_k -> region W (+ dstf floats) in A-operand order (12 row tiles of the 180 x 36 matrix; entry (tile t, k-block kb,
+    // lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 zero; per tile and lane the k-blocks 0..3 and 4..7 form two
+    // float4 — one ds_read_b128 feeds four MFMAs — and k-block 8 sits apart), by `nth` threads with index `ht`: one thread
+    // per DESTINATION float4, a 16-byte load at a 4-byte-aligned source address, one linear ds_write_b128.
+    auto stage_w = [&](const float *Wk, int dstf, int ht, int nth) {
+        struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+        f4v *dst4 = reinterpret_cast<f4v *>(s_W + dstf);
+        for (int d = ht; d < 12 * 2 * 64; d += nth) {
+            const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
+            f4v v = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            if (row < NACT * 36) {
+                const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
+                v = (f4v){w.x, w.y, w.z, w.w};
+            }
+            dst4[d] = v;
+        }
+        for (int z = ht; z < 12 * 64; z += nth) {                                 // k-block 8 of every tile
+            const int ln = z & 63, row = 16 * (z >> 6) + (ln & 15);
+            s_W[dstf + W_TAIL + z] = row < NACT * 36 ? Wk[row * 36 + 9 * (ln >> 4) + 8] : 0.0f;
+        }
+    };
+    // counters in LDS for hand-offs between SUBSETS of the workgroup's waves (s_barrier takes all sixteen): a producer
+    // publishes with lds_arrive, a consumer polls with lds_await. Every awaited count is reached by waves that never
+    // wait on the waiter, so the polls terminate; the bound only guards the GPU against a logic error — a poll that runs
+    // out raises M_FAIL: the block then writes no slab and the step reports SCG_ASYNC_STEP_HANDOFF (never a silent SCG_OK).
+    auto lds_arrive = [&](int *ctr, int amount) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == __builtin_ctzll(__ballot(true))) atomicAdd(ctr, amount);
+    };
+    auto lds_await = [&](int *ctr, int want) {
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+            if (++spins > (1 << 20)) { s_misc[M_FAIL] = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // The block's option (value function B of the merged pass): the option k >= 1 whose envs are exactly the positions
+    // [0, m) of the block — what the chunked env order of SPEC §5 produces. Its update items are then a prefix of every
+    // action run of the root's list. A gestating option never qualifies (its items are not its own envs). Every wave
+    // derives the same (kB, mB) from s_ot.
+    int kB = -1, mB = 0;
+    auto decide_b = [&]() {
+        kB = -1; mB = 0;
+        if (MODE != MODE_FUSED || nb <= 0) return;
+        const int k0 = s_ot[0];
+        if (k0 < 1 || k0 >= A.n_vf || ((A.gest >> k0) & 1u)) return;
+        int m = 0;
+        bool prefix = true;
+#pragma unroll
+        for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
+            const int i = 64 * h + lane;
+            const uint64_t mk = __ballot(i < nb && s_ot[i] == k0);
+            const int c = __popcll(mk);
+            if (mk != (c == 64 ? ~0ull : ((1ull << c) - 1ull))) prefix = false;       // the chunk's k0 envs are its first c positions
+            if (c > 0 && m != 64 * h) prefix = false;                                 // ... and every earlier chunk is full
+            m += c;
+        }
+        if (prefix) { kB = k0; mB = m; }
+    };
+    // With learning on, waves 8..15 ("helpers") have nothing to do in phase P: they stage W_0 (and W_kB), take Z_d^1 of
+    // the entry states, build the root's update list and run U1 of both value functions under it.
+    const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
+
+    // ------------------------------------------------------------------ phase P
+    if (helpers && wave < P_WAVES) __builtin_amdgcn_s_setprio(2);   // phase P is the critical path
+    if (wave < P_WAVES) {                             // one lane per env on P_WAVES full waves
+        const int i = tid;
+        const bool valid = i < nb;
+        const int e = (MODE == MODE_FUSED && A.perm && valid) ? A.perm[e0 + i] : e0 + i;
+        if (MODE == MODE_FUSED) {
+            uint32_t u[4] = {0u, 0u, 0u, 0u};
+            int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
+            float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
+            if (valid) {
+                // act (SPEC §2, §4.3)
+                const uint64_t gid = (uint64_t)(A.env_base + e);
+                philox4x32_10((uint32_t)gid, (uint32_t)(A.t & 0xffffffffu), (uint32_t)(A.t >> 32), 0u,
+                              (uint32_t)(A.seed & 0xffffffffu), (uint32_t)(A.seed >> 32), u);
+                const bool explore = (float)(u[0] >> 8) * 0x1p-24f < A.epsilon;
+                const int a_rand = (int)__umulhi(u[1], 5u);
+                int a_greedy = 0;
+                float best = A.qcache[e];
+#pragma unroll
+                for (int aa = 1; aa < NACT; ++aa) {
+                    const float q = A.qcache[(size_t)aa * N + e];
+                    if (q > best) { best = q; a_greedy = aa; }
+                }
+                a = explore ? a_rand : a_greedy;
+                SCG_STAMP(16);                                        // P: perm + qcache gathers, Philox, action
+                sx = A.x[e]; sy = A.y[e]; svx = A.vx[e]; svy = A.vy[e];
+                ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];
+                s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
+                s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
+                s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o;
+            } else {
+                s_a[i] = 0; s_ot[i] = 255;
+            }
+            if (helpers) lds_arrive(&s_misc[M_C_PUB], 64);                        // state, action and option id of this wave's envs are out
+            // physics (SPEC §1.3), the whole wave together
+            bool goal;
+            SCG_STAMP(17);                                        // P: state gathers
+            // the envs' own wave settles free flight and lists the (env, candidate edge) pairs of the others in groups of 64;
+            // the groups of ALL env waves are then dealt to waves 0..P_POOL-1
+            bool par;
+            float *xs_mine = s_s + 4 * BLOCK_ENVS + wave * 64;
+            const int groups = pinball_wave_prepare_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal, par,
+                                                        s_pitems + wave * PITEMS, xs_mine, BLOCK_ENVS);
+            if (lane == 0) s_misc[M_GROUPS + wave] = groups;
+            lds_arrive(&s_misc[M_C_PREP], 1);
+            SCG_STAMP(18);                                        // P: physics, own part (refinement, free flight, pair lists)
+            {
+                lds_await(&s_misc[M_C_PREP], P_WAVES);
+                int gsum[P_WAVES + 1];
+                gsum[0] = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[M_GROUPS + w2];
+                for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
+                    int owner = 0, first = 0;
+#pragma unroll
+                    for (int w2 = 1; w2 < P_WAVES; ++w2) if (q >= gsum[w2]) { owner = w2; first = gsum[w2]; }
+                    pinball_wave_group(s_edges, A.ms, s_pitems + owner * PITEMS + 64 * (q - first),
+                                       s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
+                }
+                lds_arrive(&s_misc[M_C_POOL], 1);
+                lds_await(&s_misc[M_C_POOL], P_POOL);
+            }
+            const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
+            SCG_STAMP(2);                                         // P: physics, the pooled pair groups + hand-offs
+            if (valid) {
+                // bookkeeping (SPEC §1.4)
+                const int eps1 = ep0 + 1;
+                const bool timeout = !goal && eps1 >= A.max_ep;
+                const int dn = goal ? 1 : (timeout ? 2 : 0);
+                float nx = sx, ny = sy, nvx = svx, nvy = svy;
+                if (dn) {
+                    const uint32_t si = __umulhi(u[2], (uint32_t)A.ms.n_starts);
+                    nx = A.starts[2 * si]; ny = A.starts[2 * si + 1]; nvx = 0.0f; nvy = 0.0f;
+                }
+                s_s[4 * BLOCK_ENVS + i] = nx; s_s[5 * BLOCK_ENVS + i] = ny;
+                s_s[6 * BLOCK_ENVS + i] = nvx; s_s[7 * BLOCK_ENVS + i] = nvy;
+                // options (SPEC §4.2), branch-free: membership bit masks of s' and s_next over all options
+                unsigned inA = 0, inB = 0, inS = 0;   // bit k: in_k(s'), in_k(s_next); gestating k only: in_k(s)
+                const unsigned known = A.enabled | A.gest;
+#pragma unroll
+                for (int k = 1; k < MAX_VF; ++k) {
+                    if (k < A.n_vf && ((known >> k) & 1u)) {
+                        const float *w = s_clf + CLF_STRIDE * k;
+                        if (clf_z(w, sx, sy) > 0.0f) inA |= 1u << k;
+                        if (clf_z(w, nx, ny) > 0.0f) inB |= 1u << k;
+                        if (((A.gest >> k) & 1u) && clf_z(w, s_s[0 * BLOCK_ENVS + i], s_s[1 * BLOCK_ENVS + i]) > 0.0f) inS |= 1u << k;
+                    }
+                }
+                bool keep = false;
+                float ro = 0.0f, co = 0.0f;
+                if (o >= 1) {
+                    const unsigned par2 = (A.parents >> (3 * (o & 7))) & 7u;       // SPEC §4.2: target of option o
+                    const bool succ = (par2 == 0) ? goal : ((inA >> par2) & 1u);
+                    const bool fail = !succ && !((inA >> (o & 31)) & 1u);
+                    const bool otime = osteps + 1 >= A.max_opt;
+                    const bool term = (dn != 0) || succ || fail || otime;
+                    ro = rew + (succ ? A.r_succ : 0.0f);
+                    co = term ? 0.0f : A.gamma;
+                    keep = !term;
+                }
+                // smallest k with in_k(s_next) and s_next outside k's target region
+                unsigned tgtB = 0;                    // bit k: s_next already lies in option k's target region
+#pragma unroll
+                for (int k = 1; k < MAX_VF; ++k) {
+                    const unsigned par2 = (A.parents >> (3 * k)) & 7u;
+                    if (par2 != 0 && ((inB >> par2) & 1u)) tgtB |= 1u << k;
+                }
+                const unsigned sel = inB & ~tgtB & A.enabled;         // a gestating option is never selected
+                const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
+                s_on[i] = (uint8_t)on;
+                s_gs[i] = (uint8_t)inS; s_ia[i] = (uint8_t)((inA & 0x3Eu) | (goal ? 1u : 0u));
+                {   // bit masks of the VFs with items / update items here: OR over the wave's lanes first, then one LDS atomic per wave
+                    const unsigned pm = (1u << (o & 31)) | (1u << (on & 31)) | inS, um = (1u << (o & 31)) | inS;
+                    unsigned pw = 0, uw = 0;
+#pragma unroll
+                    for (int k = 0; k < MAX_VF + 1; ++k) {
+                        if (__ballot((pm >> k) & 1u)) pw |= 1u << k;
+                        if (__ballot((um >> k) & 1u)) uw |= 1u << k;
+                    }
+                    if (lane == __builtin_ctzll(__ballot(true))) {
+                        atomicOr(reinterpret_cast<unsigned *>(&s_misc[M_PRESENT]), pw);
+                        atomicOr(reinterpret_cast<unsigned *>(&s_misc[M_UPD]), uw);
+                    }
+                }
+                if (inS && A.gest_succ) {                             // SPEC §4.4: gestation successes (integer counts: order-free)
+#pragma unroll
+                    for (int k = 1; k < MAX_VF; ++k) {
+                        const unsigned par2 = (A.parents >> (3 * k)) & 7u;
+                        if (((inS >> k) & 1u) && ((par2 == 0) ? goal : (bool)((inA >> par2) & 1u))) atomicAdd(&A.gest_succ[k], 1);
+                    }
+                }
+                s_r0[i] = rew; s_c0[i] = dn ? 0.0f : A.gamma; s_ro[i] = ro; s_co[i] = co;
+                // results -> staging record at this env's POSITION (full-line stores); commit_row scatters them
+                // to the caller's arrays in env order
+                {
+                    const int osn = keep ? osteps + 1 : 0, epn = dn ? 0 : eps1;
+                    float4 *orec = A.outrec + (size_t)(e0 + i) * 4;
+                    orec[0] = make_float4(nx, ny, nvx, nvy);
+                    orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
+                                          __int_as_float(osn), __int_as_float(epn));
+                }
+                SCG_STAMP(19);                                        // P: bookkeeping, option logic, result line
+                if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
+                    const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
+                    A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
+                }
+                if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
+                if (A.hist_next) atomicAdd(&A.hist_next[(e >> 8) * 8 + on], 1);   // next step's counting sort
+            } else {
+                s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
+            }
+        } else if (valid) {
+            if (MODE == MODE_TRANS) {
+                s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
+                s_s[2 * BLOCK_ENVS + i] = A.vx[e]; s_s[3 * BLOCK_ENVS + i] = A.vy[e];
+                s_s[4 * BLOCK_ENVS + i] = A.xn[e]; s_s[5 * BLOCK_ENVS + i] = A.yn[e];
+                s_s[6 * BLOCK_ENVS + i] = A.vxn[e]; s_s[7 * BLOCK_ENVS + i] = A.vyn[e];
+                s_a[i] = A.action[e]; s_ot[i] = (uint8_t)A.k_lo; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
+                const float r = A.reward[e], c = A.cont_in[e];
+                s_r0[i] = r; s_c0[i] = c; s_ro[i] = r; s_co[i] = c;
+            } else {
+                s_s[4 * BLOCK_ENVS + i] = A.x[e]; s_s[5 * BLOCK_ENVS + i] = A.y[e];
+                s_s[6 * BLOCK_ENVS + i] = A.vx[e]; s_s[7 * BLOCK_ENVS + i] = A.vy[e];
+                s_a[i] = 0; s_ot[i] = 255; s_on[i] = (uint8_t)A.k_lo; s_gs[i] = 0; s_ia[i] = 0;
+                s_r0[i] = 0.0f; s_c0[i] = 0.0f; s_ro[i] = 0.0f; s_co[i] = 0.0f;
+            }
+        } else {
+            s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
+        }
+    } else if (MODE == MODE_FUSED && wave < P_POOL) {   // no envs of its own: takes its share of the physics' pair groups
+        lds_await(&s_misc[M_C_PREP], P_WAVES);
+        int gsum[P_WAVES + 1];
+        gsum[0] = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[M_GROUPS + w2];
+        for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
+            int owner = 0, first = 0;
+#pragma unroll
+            for (int w2 = 1; w2 < P_WAVES; ++w2) if (q >= gsum[w2]) { owner = w2; first = gsum[w2]; }
+            pinball_wave_group(s_edges, A.ms, s_pitems + owner * PITEMS + 64 * (q - first),
+                               s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
+        }
+        lds_arrive(&s_misc[M_C_POOL], 1);
+    } else if (helpers && wave >= HELPER0) {
+        const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index
+        constexpr int NHT = N_HELP * 64;
+        stage_w(A.W, 0, ht, NHT);
+        lds_await(&s_misc[M_C_PUB], 64 * P_WAVES);                                     // the P waves have published s, a and the option ids
+        decide_b();
+        if (kB >= 1) stage_w(A.W + (size_t)kB * NACT * NF, W_FLOATS, ht, NHT);
+        for (int u = ht; u < BLOCK_ENVS * 2; u += NHT) {                               // Z_d^1 of the entry states, two variables per thread
+            const int i = u & (BLOCK_ENVS - 1), h = u / BLOCK_ENVS;
+            if (i < nb) {
+                const float v0 = s_s[(2 * h) * BLOCK_ENVS + i], v1 = s_s[(2 * h + 1) * BLOCK_ENVS + i];
+                const float2 za = sincospi_cs(h ? fmaf(v0, 0.25f, 0.5f) : v0), zb = sincospi_cs(h ? fmaf(v1, 0.25f, 0.5f) : v1);
+                *reinterpret_cast<float4 *>(s_z1 + (i * 2 + 0) * 4 + 2 * h) = make_float4(za.x, za.y, zb.x, zb.y);
+            }
+        }
+        // the root's update list (every env, one run per action, block order inside a run): each helper wave derives the
+        // run geometry itself from ballots; helper wave 0 writes the list
+        {
+            uint64_t mk[P_WAVES][NACT];
+            int at[P_WAVES];
+#pragma unroll
+            for (int h = 0; h < P_WAVES; ++h) at[h] = 64 * h + lane < nb ? (int)s_a[64 * h + lane] : -1;
+            int off = 0;
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {
+                int rl = 0, nbq = 0;
+#pragma unroll
+                for (int h = 0; h < P_WAVES; ++h) {
+                    mk[h][a] = __ballot(at[h] == a);
+                    rl += __popcll(mk[h][a]);
+                    const int lim = mB - 64 * h;                                      // positions below mB belong to option kB
+                    const uint64_t pre = lim >= 64 ? ~0ull : (lim > 0 ? ((1ull << lim) - 1ull) : 0ull);
+                    nbq += __popcll(mk[h][a] & pre);
+                }
+                run_len[a] = rl; run_off[a] = off; nBa[a] = nbq; off += rl;
+            }
+            if (hw == 0) {
+                const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int a = 0; a < NACT; ++a) {
+                    int before = 0;
+#pragma unroll
+                    for (int h = 0; h < P_WAVES; ++h) {
+                        if (at[h] == a) s_ulist[run_off[a] + before + __popcll(mk[h][a] & below)] = (uint16_t)(64 * h + lane);
+                        before += __popcll(mk[h][a]);
+                    }
+                }
+            }
+        }
+        lds_arrive(&s_misc[M_C_HELP], 1);
+        lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
+        run_u1(hw, N_HELP, 0);
+#ifdef SCG_STAMPS
+        if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
+#endif
+    }
+    if (helpers) { if (wave < LIST_WAVES) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    block_lds_sync();
+
+    SCG_STAMP(0);   // phase P
+    // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s_next (and of s where no helper did it)
+    for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {
+        const int i = u & (BLOCK_ENVS - 1), d = (u / BLOCK_ENVS) & 3, sg = u / (4 * BLOCK_ENVS);
+        if (i < nb && (MODE != MODE_QVAL || sg == 1) && !(helpers && sg == 0)) {
+            const float sv = s_s[(4 * sg + d) * BLOCK_ENVS + i];
+            s_z1[(i * 2 + sg) * 4 + d] = sincospi_cs(d < 2 ? sv : fmaf(sv, 0.25f, 0.5f));
+        }
+    }
+    if (!(helpers && wave >= HELPER0)) decide_b();          // (the helper waves know it already)
+    if (A.k_hi < 0) { kB = -1; mB = 0; }
+
+    // ------------------------------------------------------------------ phase TD (SPEC §3.1, §5) on the matrix pipe
+    const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_PRESENT]) : ~0u;
+    const unsigned updm = (MODE == MODE_FUSED) ? (A.learn ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_UPD]) : 0u) : ~0u;
+    // Passes: pass 0 = the merged pass (value function A = the root — or the caller's VF in the un-fused modes — and B = the
+    // block's option, if any); then one single-VF pass per other value function with update items here. Value functions
+    // that only have envs ENTERING them (no update item) skip the pass machinery: see the tail of the kernel.
+    unsigned single = (MODE == MODE_FUSED && A.k_hi >= 0) ? (updm & present & ~1u & ~(kB >= 1 ? 1u << kB : 0u)) : 0u;
+    const unsigned eval_only = (MODE == MODE_FUSED && A.k_hi >= 0) ? (present & ~updm & ~1u & ~(kB >= 1 ? 1u << kB : 0u)) : 0u;
+    if (MODE == MODE_FUSED && tid < A.n_vf && A.cnts && tid != 0 && tid != kB && !((single >> tid) & 1u))
+        A.cnts[(size_t)b * A.n_vf + tid] = 0;               // value functions without a pass here leave no slab
+    const int n_pass0 = A.k_hi >= A.k_lo ? 1 : 0;
+    for (int pass = 0; pass < n_pass0 + MAX_VF; ++pass) {
+        int kA, kBp;                                        // value functions of this pass (kBp < 0: none)
+        bool dense;                                         // E over position groups (pass 0) or over the compacted eval list
+        if (pass == 0) {
+            if (!n_pass0) continue;
+            kA = MODE == MODE_FUSED ? 0 : A.k_lo; kBp = kB; dense = true;
+        } else {
+            if (!single) break;
+            kA = __builtin_ctz(single); single &= single - 1; kBp = -1; dense = false;
+        }
+        const bool u1_done = helpers && pass == 0;          // the helper waves ran U1 and built the list under phase P
+        block_lds_sync();
+        SCG_STAMP(pass == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
+        // ---- per-env flags of the pass (SPEC §5): ev bit v = the env needs Q_v(s_next, .) (bootstrap target and/or next
+        // action); update items of A (all of them in pass 0 of a fused step: the root updates on every env) with their action
+        bool evA = false, evB = false, up = false;
+        int at = -1;
+        if (tid < nb) {
+            const int ot = s_ot[tid], on = s_on[tid];
+            const bool own = (MODE == MODE_FUSED && kA == 0) || ot == kA;
+            const bool gst = MODE == MODE_FUSED && !own && ((s_gs[tid] >> kA) & 1);       // SPEC §4.4 off-policy item
+            up = (MODE != MODE_QVAL) && A.learn && (own || gst);
+            float rk = s_r0[tid], cont = s_c0[tid];
+            if (MODE == MODE_FUSED && kA != 0) {
+                if (ot == kA) { rk = s_ro[tid]; cont = s_co[tid]; }
+                else {                                    // as if the env ran option kA: no time-out, no selection
+                    const unsigned ia = s_ia[tid], par2 = (A.parents >> (3 * kA)) & 7u;
+                    const bool succ = (par2 == 0) ? (ia & 1u) : ((ia >> par2) & 1u);
+                    const bool fail = !succ && !((ia >> kA) & 1u);
+                    rk = rk + (succ ? A.r_succ : 0.0f);
+                    cont = (cont == 0.0f || succ || fail) ? 0.0f : A.gamma;
+                }
+                s_rk[tid] = rk; s_ck[tid] = cont;
+            }
+            evA = (on == kA) || (up && cont > 0.0f);
+            if (kBp >= 1) evB = (on == kBp) || (ot == kBp && A.learn && s_co[tid] > 0.0f);
+            at = s_a[tid];
+            s_ev[tid] = (uint8_t)((evA ? 1 : 0) | (evB ? 2 : 0));
+        }
+        // compacted list: single passes -> the eval items of A; pass 0 -> the envs that need Q_B but lie outside B's prefix groups
+        const int pg_b = (mB + 7) >> 3;                     // position groups that hold B's prefix
+        const bool cmp = dense ? (evB && (tid >> 3) >= pg_b) : evA;
+        uint64_t mb[1 + NACT];
+        if (wave < LIST_WAVES) {
+            mb[0] = __ballot(cmp);
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) mb[1 + a] = __ballot(up && at == a);
+            const int lim = (kBp >= 1 ? mB : 0) - 64 * wave;                          // positions below mB belong to option kB
+            const uint64_t pre = lim >= 64 ? ~0ull : (lim > 0 ? ((1ull << lim) - 1ull) : 0ull);
+            if (lane < 1 + 2 * NACT) {
+                const int sl = lane <= NACT ? lane : lane - NACT;
+                const uint64_t mine = sl == 0 ? mb[0] : sl == 1 ? mb[1] : sl == 2 ? mb[2] : sl == 3 ? mb[3] : sl == 4 ? mb[4] : mb[5];
+                s_misc[M_CNT + wave * 16 + lane] = __popcll(lane <= NACT ? mine : (mine & pre));
+            }
+            if (dense) {                                    // per position group: which value functions need it
+                const uint64_t ma = __ballot(evA), mbb = __ballot(evB);
+                if (lane < 8) {
+                    const int pgrp = wave * 8 + lane;
+                    s_eflag[pgrp] = (uint8_t)((((ma >> (8 * lane)) & 0xffull) ? 1 : 0) | ((((mbb >> (8 * lane)) & 0xffull) && pgrp < pg_b) ? 2 : 0));
+                }
+            }
+        }
+        SCG_STAMP(23);                                       // (diagnostic) flags + ballots
+        if (!u1_done) {                                      // (the helper waves staged W_0 / W_kB under phase P)
+            const float *Wa = A.W + (MODE == MODE_QVAL ? 0 : (size_t)kA * NACT * NF);
+            stage_w(Wa, 0, tid, THREADS);
+            if (kBp >= 1) stage_w(A.W + (size_t)kBp * NACT * NF, W_FLOATS, tid, THREADS);
+        }
+        SCG_STAMP(24);                                       // (diagnostic) W staging
+        block_lds_sync();
+        SCG_STAMP(25);                                       // (diagnostic) wait at the barrier behind the staging
+        int n_cmp = 0, nupdB = 0;
+        {
+            int se = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < LIST_WAVES; ++w2) se += s_misc[M_CNT + w2 * 16];
+            n_cmp = __builtin_amdgcn_readfirstlane(se);
+            int off = 0;
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {      // wave-uniform: keep them in SGPRs (the helper waves hold the same values already)
+                int sr = 0, sb = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < LIST_WAVES; ++w2) { sr += s_misc[M_CNT + w2 * 16 + 1 + a]; sb += s_misc[M_CNT + w2 * 16 + 1 + NACT + a]; }
+                run_len[a] = __builtin_amdgcn_readfirstlane(sr);
+                nBa[a] = __builtin_amdgcn_readfirstlane(sb);
+                run_off[a] = off;
+                off += run_len[a];
+                nupdB += nBa[a];
+            }
+        }
+        const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
+        if (wave < LIST_WAVES) {
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (cmp) {
+                int off = 0;
+                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[M_CNT + w2 * 16];
+                s_elist[off + __popcll(mb[0] & below)] = (uint16_t)tid;
+            }
+            if (up && !u1_done) {
+                int off = 0;
+                const uint64_t mine = at == 0 ? mb[1] : at == 1 ? mb[2] : at == 2 ? mb[3] : at == 3 ? mb[4] : mb[5];
+                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[M_CNT + w2 * 16 + 1 + at];
+                s_ulist[sel5(run_off, at) + off + __popcll(mine & below)] = (uint16_t)tid;
+            }
+        }
+        block_lds_sync();
+        if (tid == 0 && A.cnts) {
+            A.cnts[(size_t)b * A.n_vf + kA] = nupd;
+            if (kBp >= 1) A.cnts[(size_t)b * A.n_vf + kBp] = nupdB;
+        }
+        SCG_STAMP(pass == 0 ? 1 : 8);    // phase Z (first pass only) + list build + W staging
+        // ---- E: Q_v(s_next, .), one 8-item column block per wave-iteration (SPEC §3.1); the tables of a block are built
+        // once and serve both value functions. Units [0, npg) are position groups (dense pass), the rest 8-item blocks of
+        // the compacted list.
+        const int npg = dense ? (nb + 7) >> 3 : 0;
+        const int n_units = npg + ((n_cmp + 7) >> 3);
+        if (n_units + nupd == 0) continue;
+        for (int u = wave; u < n_units; u += WAVES) {
+            const bool du = u < npg;
+            const int base = du ? 8 * u : 8 * (u - npg);
+            const int cnt = du ? min(8, nb - base) : min(8, n_cmp - base);
+            const unsigned fl = du ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_eflag[u]) : (dense ? 2u : 1u);
+            if (!fl) continue;
+            {
+                const int j = min(bi, cnt - 1);
+                build_tables(du ? base + j : (int)s_elist[base + j], 1);
+            }
+            wave_lds_sync();
+            float B[9];
+#pragma unroll
+            for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+            const bool have = ocol_item < cnt;
+            const int il = du ? base + min(ocol_item, cnt - 1) : (int)s_elist[base + min(ocol_item, cnt - 1)];
+#pragma unroll 1
+            for (int v = 0; v < 2; ++v) {
+                if (!((fl >> v) & 1u)) continue;
+                f4v acc[12];
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    const f4v a0 = w4[v * (W_FLOATS / 4) + (t * 2) * 64], a1 = w4[v * (W_FLOATS / 4) + (t * 2 + 1) * 64];
+                    const float a8 = w8[v * W_FLOATS + t * 64];
+                    f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
+                }
+                // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
+                float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {
+                    const int Ct = (16 * t) % 36, At = (16 * t) / 36;
+                    if (Ct + 12 < 36) {                          // the tile's 16 rows belong to one action
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + Ct);
+#pragma unroll
+                        for (int vv = 0; vv < 4; ++vv) q[At] = fmaf(acc[t][vv], ab4[vv], q[At]);
+                    } else {                                     // row groups g >= (36 - Ct) / 4 belong to the next action
+                        const bool wrap = 4 * g >= 36 - Ct;
+                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + (wrap ? Ct - 36 : Ct));
+                        float xq = wrap ? q[At + 1] : q[At];
+#pragma unroll
+                        for (int vv = 0; vv < 4; ++vv) xq = fmaf(acc[t][vv], ab4[vv], xq);
+                        q[At] = wrap ? q[At] : xq;
+                        q[At + 1] = wrap ? xq : q[At + 1];
+                    }
+                }
+                float qo[NACT] = {q[0], q[1], q[2], q[3], q[4]};
+                item_tree_sum<NACT>(qo);
+                if (out_lane && have && ((s_ev[il] >> v) & 1)) {
+                    const int kv = v ? kBp : kA;
+                    if (s_on[il] == kv) {
+                        if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
+                            float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                            orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                            orec[3].x = qo[4];
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + e0 + il], qo[a]);
+                        }
+                    }
+                    float mx = qo[0];
+#pragma unroll
+                    for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
+                    s_maxq[v * BLOCK_ENVS + il] = mx;
+                }
+            }
+            wave_lds_sync();
+        }
+        SCG_STAMP(pass == 0 ? 3 : 10);   // E (wave 0's share)
+        // ---- U1 (pass 0 of a learning step: ran under phase P on the helper waves)
+        if (MODE != MODE_QVAL && nupd > 0 && !u1_done) run_u1(wave, WAVES, n_units);   // dealt on behind E's blocks
+        if (MODE == MODE_QVAL || nupd == 0) continue;
+        SCG_STAMP(pass == 0 ? 4 : 11);   // U1 (wave 0's share)
+        block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
+        SCG_STAMP(pass == 0 ? 7 : 14);   // wait for the other waves
+
+        // ---- U2: the block partials (SPEC §5). Padded slots: every action run of A's list is padded with null items to a
+        // multiple of 4, run a occupying slots [off4[a], off4[a + 1]). Chunks of U2_CH = 144 slots (kap = 2 slot + part):
+        //   build  CDT[c34][kap] = CD, PT_A[c12][kap] = delta_A ABsel and, for the first len4B[a] slots of run a,
+        //          PT_B[c12][kap] = delta_B ABsel (null items: +0); wave w owns slots 9 w .. 9 w + 8
+        //   MFMA   G_v[a] += PT_v x CDT^T, groups of 4 items: one MFMA over their real parts, one over the imaginary parts;
+        //          the 9 output tiles of (v, a) are jobs J = 45 v + 9 a + q dealt to the waves (J mod 16), accumulators stay
+        //          in registers for the whole pass and go straight to the block's slabs
+        int off4[NACT + 1], len4B[NACT];
+        off4[0] = 0;
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) { off4[a + 1] = off4[a] + ((run_len[a] + 3) & ~3); len4B[a] = (nBa[a] + 3) & ~3; }
+        int wave_u = wave;
+        asm volatile("" : "+s"(wave_u));                    // keeps the per-(wave, job) tile geometry inside the pass
+        const int n_jobs = nupdB > 0 ? 2 * NACT * 9 : NACT * 9;
+        constexpr int JOBS = (2 * NACT * 9 + WAVES - 1) / WAVES;      // job slots per wave
+        f4v accU[JOBS];
+#pragma unroll
+        for (int s = 0; s < JOBS; ++s) accU[s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+        float *ptabA = s_R, *ptabB = s_R + 36 * US, *ctab = s_R + 2 * 36 * US;
+        const float *rA = (MODE == MODE_FUSED && kA != 0) ? s_rk : s_r0, *cA = (MODE == MODE_FUSED && kA != 0) ? s_ck : s_c0;
+        const int bi9 = lane % 9, cp9 = lane / 9;           // builder lanes of a chunk: (slot 9 wave + bi9, second index cp9 < 6)
+        for (int ch0 = 0; ch0 < off4[NACT]; ch0 += U2_CH) {
+            if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
+            SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
+            {
+                const int slot = 9 * wave + bi9, ps = ch0 + slot;
+                if (cp9 < 6 && ps < off4[NACT]) {
+                    int a_ = 0;
+#pragma unroll
+                    for (int a = 1; a < NACT; ++a) a_ += ps >= off4[a] ? 1 : 0;
+                    const int o4 = a_ == 0 ? off4[0] : a_ == 1 ? off4[1] : a_ == 2 ? off4[2] : a_ == 3 ? off4[3] : off4[4];
+                    const int rl = sel5(run_len, a_), ro = sel5(run_off, a_), nbq = sel5(nBa, a_), l4b = sel5(len4B, a_);
+                    const int j = ps - o4;
+                    float *pdA = ptabA + cp9 * US + 2 * slot, *pdB = ptabB + cp9 * US + 2 * slot, *cdst = ctab + cp9 * US + 2 * slot;
+                    if (j < rl) {
+                        const int li = ro + j, il = s_ulist[li];
+                        const float rr = rA[il], cont = cA[il];
+                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
+                        const float d = target - s_qsa[li];
+                        float2 ab[6], cd[6];
+                        item_entries(s_z1 + (il * 2 + 0) * 4, cp9, ab, cd);
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            *reinterpret_cast<float2 *>(pdA + 6 * c * US) = make_float2(d * ab[c].x, d * (-ab[c].y));
+                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(cd[c].x, cd[c].y);
+                        }
+                        if (j < nbq) {                           // the item also updates value function B
+                            const float rb = s_ro[il], cb2 = s_co[il];
+                            const float tb = cb2 > 0.0f ? fmaf(cb2, s_maxq[BLOCK_ENVS + il], rb) : rb;
+                            const float db = tb - s_qsa[BLOCK_ENVS + li];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c)
+                                *reinterpret_cast<float2 *>(pdB + 6 * c * US) = make_float2(db * ab[c].x, db * (-ab[c].y));
+                        } else if (j < l4b) {                    // null item of B's run (its C operand is masked in the MFMA loop)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) *reinterpret_cast<float2 *>(pdB + 6 * c * US) = make_float2(0.0f, 0.0f);
+                        }
+                    } else {                                     // null item padding a run to a multiple of 4
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            *reinterpret_cast<float2 *>(pdA + 6 * c * US) = make_float2(0.0f, 0.0f);
+                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(0.0f, 0.0f);
+                        }
+                        if (j < l4b) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) *reinterpret_cast<float2 *>(pdB + 6 * c * US) = make_float2(0.0f, 0.0f);
+                        }
+                    }
+                }
+            }
+            SCG_STAMP(21);                                       // (diagnostic) U2: build
+            block_lds_sync();                                    // operands visible
+            SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
+#pragma unroll
+            for (int s = 0; s < JOBS; ++s) {
+                const int J = wave_u + WAVES * s;
+                if (J >= n_jobs) continue;
+                const int v = J >= NACT * 9 ? 1 : 0, Jr = J - NACT * 9 * v;
+                const int a = (Jr * 57) >> 9, q = Jr - 9 * a;                  // Jr / 9, Jr % 9 for Jr < 45
+                const int mi = (q * 11) >> 5, ni = q - 3 * mi;                  // q / 3, q % 3
+                const int o4 = sel5(off4, a), len = v ? sel5(len4B, a) : (((sel5(run_len, a)) + 3) & ~3);
+                const int lo = max(o4, ch0), hi = min(o4 + len, ch0 + U2_CH);   // the run's slots in this chunk
+                if (lo >= hi) continue;
+                const float *pa = (v ? ptabB : ptabA) + min(16 * mi + n16, 35) * US + 2 * g + 2 * (lo - ch0);
+                const float *pb = ctab + min(16 * ni + n16, 35) * US + 2 * g + 2 * (lo - ch0);
+                const int ngrp = (hi - lo) >> 2;
+                const int nvalid = v ? sel5(nBa, a) - (lo - o4) : (1 << 30);    // B: items of the run still real from slot lo on
+                for (int gi = 0; gi < ngrp; ++gi) {
+                    const float2 a2 = *reinterpret_cast<const float2 *>(pa + 8 * gi);
+                    float2 b2 = *reinterpret_cast<const float2 *>(pb + 8 * gi);
+                    if (v && 4 * gi + g >= nvalid) b2 = make_float2(0.0f, 0.0f);     // null item of B: both operands +0 (SPEC §5)
+                    accU[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.x, a2.x, accU[s], 0, 0, 0);
+                    accU[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.y, a2.y, accU[s], 0, 0, 0);
+                }
+            }
+        }
+        SCG_STAMP(pass == 0 ? 6 : 13);   // U2
+        // the block partials straight from the accumulators (zeros for an empty run). The tiles were accumulated
+        // TRANSPOSED (A operand = CDT rows, B operand = PT rows; fma(a, b, c) = fma(b, a, c)), so register v of lane (n16, g)
+        // of tile (mi, ni) is G[a][c12 = 16 mi + n16][c34 = 16 ni + 4 g + v]: one 16-byte store per lane and tile
+        if (!s_misc[M_FAIL]) {
+#pragma unroll
+            for (int s = 0; s < JOBS; ++s) {
+                const int J = wave_u + WAVES * s;
+                if (J >= n_jobs) continue;
+                const int v = J >= NACT * 9 ? 1 : 0, Jr = J - NACT * 9 * v;
+                const int a = (Jr * 57) >> 9, q = Jr - 9 * a;
+                const int mi = (q * 11) >> 5, ni = q - 3 * mi;
+                const int kv = v ? kBp : kA;
+                const bool okl = (mi < 2 || n16 < 4) && (ni < 2 || g == 0);
+                float *slab_lane = A.slabs + ((size_t)b * A.n_vf + kv) * NACT * NF + n16 * 36 + 4 * g;
+                if (okl) store_wt(slab_lane + a * NF + (16 * mi) * 36 + 16 * ni, accU[s]);
+            }
+        } else if (tid == 0 && A.cnts) {
+            A.cnts[(size_t)b * A.n_vf + kA] = 0;
+            if (kBp >= 1) A.cnts[(size_t)b * A.n_vf + kBp] = 0;
+        }
+        SCG_STAMP(15);                // slab stores issued
+    }
+    // ------------------------------------------------------------------ evaluation-only value functions, on the vector pipe
+    // Q_k(s_next, .) of the few envs entering an option nobody in this workgroup runs. The (value function, env) pairs are
+    // enumerated in a fixed order by every wave and dealt round-robin; a wave evaluates its pair alone, with W_k read
+    // straight from global memory (one 36-float row per lane and round) — no staging, no lists, no workgroup barrier. The
+    // arithmetic is SPEC §3.1 operation for operation (the MFMA is the same fmaf chain), so the result is bit-identical to
+    // what a pass would have produced.
+    if (MODE == MODE_FUSED && eval_only && A.k_hi >= 0) {
+        block_lds_sync();                                   // region R is free again
+        SCG_STAMP(26);
+        float2 *t_ab = reinterpret_cast<float2 *>(cdk), *t_cd = t_ab + 36, *t_T = t_cd + 36;      // this wave's table area: 36 + 36 + 180 float2
+        int pair = 0;
+        for (int k = 1; k < A.n_vf; ++k) {
+            if (!((eval_only >> k) & 1u)) continue;
+            const float *Wk = A.W + (size_t)k * NACT * NF;
+            for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
+                const int ii = 64 * h + lane;
+                uint64_t m = __ballot(ii < nb && s_on[ii] == k);
+                while (m) {
+                    const int il = 64 * h + (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if ((pair++ & (WAVES - 1)) != wave) continue;
+                    // tables of s_next: lane c < 36 owns AB[c] and CD[c] (c = 6 hi + lo)
+                    if (lane < 36) {
+                        const float4 *zp = reinterpret_cast<const float4 *>(s_z1 + (il * 2 + 1) * 4);
+                        const float4 za = zp[0], zc = zp[1];
+                        const int hi = (lane * 43) >> 8, lo = lane - 6 * hi;                  // lane / 6, lane % 6 for lane < 36
+                        float2 ab = zpow_sel(make_float2(za.z, za.w), lo), cd = zpow_sel(make_float2(zc.z, zc.w), lo);
+#pragma unroll
+                        for (int c = 1; c < 6; ++c) {                                         // row hi: hi chained products
+                            const float2 abn = cmul(ab, make_float2(za.x, za.y)), cdn = cmul(cd, make_float2(zc.x, zc.y));
+                            if (c <= hi) { ab = abn; cd = cdn; }
+                        }
+                        t_ab[lane] = make_float2(ab.x, -ab.y);
+                        t_cd[lane] = cd;
+                    }
+                    wave_lds_sync();
+                    // T[row][re | im], row = 36 a + c12: the fmaf chain over c34 = 9 g + kb (kb outer, g inner)
+#pragma unroll 1
+                    for (int r0 = 0; r0 < 192; r0 += 64) {
+                        const int row = r0 + lane;
+                        if (row < 180) {
+                            const float4 *wr = reinterpret_cast<const float4 *>(Wk + row * 36);
+                            float wv[36];
+#pragma unroll
+                            for (int q4 = 0; q4 < 9; ++q4) {
+                                const float4 w = wr[q4];
+                                wv[4 * q4] = w.x; wv[4 * q4 + 1] = w.y; wv[4 * q4 + 2] = w.z; wv[4 * q4 + 3] = w.w;
+                            }
+                            float tre = 0.0f, tim = 0.0f;
+#pragma unroll
+                            for (int kb = 0; kb < 9; ++kb) {
+#pragma unroll
+                                for (int gg = 0; gg < 4; ++gg) {
+                                    const float2 cdv = t_cd[9 * gg + kb];
+                                    tre = fmaf(wv[9 * gg + kb], cdv.x, tre);
+                                    tim = fmaf(wv[9 * gg + kb], cdv.y, tim);
+                                }
+                            }
+                            t_T[row] = make_float2(tre, tim);
+                        }
+                    }
+                    wave_lds_sync();
+                    // q[a][g][part]: lane = 8 a + 2 g + part chains over its nine c12 in increasing order, then the tree
+                    float qv = 0.0f;
+                    {
+                        const int a = min(lane >> 3, NACT - 1), gq = (lane >> 1) & 3, part = lane & 1;
+                        // rows 36 a + c12 of group gq: c12 = 4 i + v with ((36 a) / 4 + i) % 4 == gq  ->  i = (gq - 9 a) & 3, + 4, + 8
+                        const int i0 = (gq - 9 * a) & 3;
+#pragma unroll
+                        for (int ii3 = 0; ii3 < 3; ++ii3) {
+                            const int i = i0 + 4 * ii3;                                  // i = 0..8: quad of rows 4 i .. 4 i + 3
+                            if (i < 9) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    const float2 tv = t_T[36 * a + 4 * i + v], av = t_ab[4 * i + v];
+                                    qv = fmaf(part ? tv.y : tv.x, part ? av.y : av.x, qv);
+                                }
+                            }
+                        }
+                    }
+                    qv = qv + __shfl_xor(qv, 1, 64);                      // u_g = q_re + q_im
+                    qv = qv + __shfl_xor(qv, 2, 64);                      // u_0 + u_1 | u_2 + u_3
+                    qv = qv + __shfl_xor(qv, 4, 64);                      // (u_0 + u_1) + (u_2 + u_3)
+                    if (lane < 8 * NACT && (lane & 7) == 0)               // into the env's result line (orec[2].xyzw, orec[3].x)
+                        reinterpret_cast<float *>(A.outrec + (size_t)(e0 + il) * 4)[8 + (lane >> 3)] = qv;
+                    wave_lds_sync();
+                }
+            }
+        }
+        SCG_STAMP(27);
+    }
+    if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)
+        block_lds_sync();
+        if (tid == 0 && s_misc[M_FAIL])
+            __hip_atomic_fetch_or(A.async_word, SCG_ASYNC_STEP_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#ifdef SCG_STAMPS
+    if (MODE == MODE_FUSED && A.stamps) {
+        __syncthreads();
+        if (tid < 32) A.stamps[(size_t)blockIdx.x * 32 + tid] += s_stamp[tid];
+    }
+#endif
+}

@@ -19,7 +19,7 @@ gpu_util.scg.load_map = scg.load_map
 maps = ["pinball_simple", "pinball_maze", "pinball_empty"] + list(extra)
 ok = 0
 for c in range(n_cases):
-    n = int(rng.choice([1, 7, 63, 64, 65, 128, 129, 191, 255, 257, 500, 1000, 1500, 3000]))
+    n = int(rng.choice([1, 7, 63, 64, 65, 128, 129, 191, 255, 256, 257, 500, 511, 513, 1000, 1500, 3000]))
     nopt = int(rng.integers(0, 6)); mp = str(rng.choice(maps)); seed = int(rng.integers(0, 1 << 20))
     try:
         T.test_random_configuration_rollout_bit_exact(n, nopt, mp, seed)

@@ -39,7 +39,7 @@ def value_case():
 
 
 def step_case():
-    n, n_opt, mask, steps = 300, 2, 0b110, 4
+    n, n_opt, mask, steps = 700, 2, 0b110, 4
     orc, m = make_oracle("pinball_simple", n_envs=n, n_options=n_opt, seed=77, enabled_mask=mask)
     clf = chain_classifiers(m, n_opt)
     st = sc_oracle.new_state(n, m)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load_library()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.scg_abi_version() == 1
+    assert lib.scg_abi_version() == 2
     assert lib.scg_strerror(0) == b"ok" and b"invalid" in lib.scg_strerror(-1)
 
 

@@ -70,7 +70,7 @@ def test_hip_reproduces_golden():
     d = load("step")
     n, nopt, mask = int(d["n"]), int(d["n_options"]), int(d["mask"])
     ctx, _, m = make_pair("pinball_simple", n, n_options=nopt, seed=int(d["seed"]), enabled_mask=mask)
-    if ctx.lib.scg_block_envs() == 128:      # the step fixture pins SPEC §5's default geometry (not `make b256`)
+    if ctx.lib.scg_block_envs() == 256:      # the step fixture pins SPEC §5's geometry
         st = state_to_device({k: d[k + "0"] for k in sc_oracle.new_state(1, m)}, ctx)
         W, clf = dev(d["W0"].copy()), dev(d["clf"])
         _, n_d = ctx.grad_buffers()

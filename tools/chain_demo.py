@@ -12,9 +12,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--map", default="pinball_simple"); ap.add_argument("--envs", type=int, default=8192)
 ap.add_argument("--options", type=int, default=3); ap.add_argument("--alpha", type=float, default=0.02)
 ap.add_argument("--warm", type=int, default=3000); ap.add_argument("--after", type=int, default=3000)
+ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--gestation", type=int, default=0, help="successes a new option must see before it is enabled (SPEC 4.4)")
 a = ap.parse_args()
-ag = SkillChainingAgent(a.map, a.envs, a.options, seed=1, alpha=a.alpha, epsilon=0.05, gamma=0.99,
+ag = SkillChainingAgent(a.map, a.envs, a.options, seed=a.seed, alpha=a.alpha, epsilon=0.05, gamma=0.99,
                         max_episode_steps=2000, max_option_steps=200, r_option_success=50.0)
 ag.enable_tracing(64)
 
