@@ -149,6 +149,67 @@ def cpu_baseline(seconds_target=15.0):
                       f"on 1 thread in {d1:.1f} s; the upstream reference ships no code to time"}
 
 
+def _time_steps(agent, steps, warmup, ramp=200):
+    import torch
+    for _ in range(ramp + warmup):
+        agent.step_batch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.step_batch()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_measurements(steps, warmup):
+    """Two more single-GPU figures beside the headline (which keeps its synthetic nested-disc options so that rounds stay
+    comparable): BASELINE configs[1] (4096 envs, root + 1 chained option) and configs[2] with DISCOVERED options — the outer
+    loop (SkillChainingAgent.chain_skills: trajectory ring -> device-side trigger -> GPU logistic regression) runs untimed
+    on the 65 536-env agent until <= 5 options exist, then the steady state is timed with those classifiers."""
+    import torch
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    ex = {}
+    # configs[1]
+    n1 = 4096
+    ag = SkillChainingAgent(MAP, n1, 1, seed=0, **HP)
+    ag.clf.copy_(torch.as_tensor(chain_discs(ag.map, 1)))
+    ag.enable_option(1)
+    ag.init_weights(std=1e-3, seed=0)
+    ag.domain.reset_random(seed=1000, v_max=1.0)
+    dt = _time_steps(ag, max(steps, 200), warmup)
+    ex["config1_4096_envs_root_plus_1_option"] = {"value": n1 / dt, "unit": "env-steps/s", "us_per_step": dt * 1e6,
+                                                   "workgroups": -(-n1 // scg_block_envs()), "envs_in_an_option_at_end": int((ag.state.option_id > 0).sum())}
+    del ag
+    # configs[2] on discovered options
+    hp = dict(HP, alpha=0.02, r_option_success=10000.0)       # a learning rate at which the root reaches the goal within the untimed
+    ag = SkillChainingAgent(MAP, ENVS_PER_GPU, N_OPTIONS, seed=0, **hp)     # warm-up; completion reward of the goal's scale (DESIGN: chain evidence)
+    ag.enable_tracing(64)
+    warm = 3000
+    for _ in range(warm):
+        ag.step_batch()
+    t_before = ag.t
+    report = ag.chain_skills(steps_per_option=400, min_examples=3000, max_examples=60000, start_coverage=2.0)   # never "covered": up to 5 options
+    discovery_steps = ag.t - t_before
+    ag.ctx.disarm_collect()
+    dt = _time_steps(ag, max(steps, 200), warmup)
+    per_opt = [int((ag.state.option_id == k).sum()) for k in range(N_OPTIONS + 1)]
+    ex["discovered_chain_65536_envs"] = {"value": ENVS_PER_GPU / dt, "unit": "env-steps/s", "us_per_step": dt * 1e6,
+                                          "options_created": len(report), "untimed_root_warmup_steps": warm,
+                                          "untimed_discovery_steps": discovery_steps,
+                                          "fit_accuracy": [round(float(r["accuracy"]), 3) for r in report],
+                                          "envs_per_running_option_at_end": per_opt,
+                                          "envs_in_an_option_at_end": int(sum(per_opt[1:])), "tracing": "on (trajectory ring + events)",
+                                          "hparams": hp}
+    del ag
+    torch.cuda.empty_cache()
+    return ex
+
+
+def scg_block_envs():
+    import skill_chaining_with_graphs_amd as scg
+    return int(scg.block_envs())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +225,8 @@ def main():
     ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
     ap.add_argument("--diag-fresh-sort", action="store_true", help="diagnostic: stand-alone sort kernels every step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the two extra single-GPU measurements printed beside the headline "
+                    "(BASELINE configs[1]: 4096 envs, root + 1 option; configs[2] on DISCOVERED options: chain_skills run untimed first)")
     ap.add_argument("--event-every", type=int, default=0, help="HIP event pair round every n-th fused-kernel launch "
                     "(0 = max(8, steps // 8): each pair costs a few us of queue bubble — 3 us per step when every other launch is sampled)")
     ap.add_argument("--ramp", type=int, default=200, help="untimed clock-ramp step-batches before the warm-up "
@@ -316,6 +379,10 @@ def main():
                        "note": "algorithmic flops of the direct formulation (phi, Q, accumulate: DESIGN.md) over the "
                                "dense f32 MFMA peak (= the f32 vector peak, MI355X_MICROARCH.md); the kernel runs the "
                                "contractions in factorised form on v_mfma_f32_16x16x4_f32 and issues ~1.9x these flops"}
+        if world == 1 and not args.no_extras and not (args.diag_no_td or args.diag_fresh_sort or args.no_learn):
+            del agent                                   # free the headline agent's buffers first
+            torch.cuda.empty_cache()
+            out["extras"] = extra_measurements(args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:

@@ -31,8 +31,12 @@ __device__ __forceinline__ void gstore(T *p, T v) { *p = v; }
 // leaves the lines dirty in the XCD's L2 and the kernel boundary then waits for their write-back (MI355X_MICROARCH.md, "boundary":
 // + B / 6 TB/s); written through, they are in the memory-side cache by then, where the reduce launch (other XCDs) reads them
 // anyway: +1.1 % env-steps/s. (`nt` stores, round 2, bypassed that cache too and cost the reduce launch 5.7 us.)
+// The trailing s_nop is part of the instruction's contract here: gfx9 reads the data VGPRs of a store wider than 8 bytes a
+// few cycles AFTER issue, and a vector write to one of them in the next two wait states corrupts the stored value. hipcc's
+// hazard recognizer pads its own stores; inline asm is opaque to it (round 4: the compiler reused v[26:27] of the data for the
+// next address right behind the store and 4 x 8 entries of a tile came out as address bits — tools/debug_u2.py found it).
 __device__ __forceinline__ void store_wt(float *p, f4v v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" :: "v"(p), "v"(v) : "memory");
 }
 
 struct StepArgs {

@@ -75,10 +75,22 @@ constexpr int M_C_PUB = 71;       //   envs whose state and action are published
 constexpr int M_PRESENT = 72;     // bit k: some env here has an item for VF k
 constexpr int M_UPD = 73;         // bit k: ... an UPDATE item
 constexpr int M_FAIL = 74;        // a bounded hand-off poll ran out (reported through the async status word)
+constexpr int M_C_PUBS = 77;      //   envs whose entry state and option id are published (the actions follow: M_C_PUB)
+constexpr int M_KB = 75, M_MB = 76; // the block's option (value function B of the merged pass) and its prefix length, published by wave HELPER0
 constexpr int M_INTS = 128;
 static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
+// wave priorities (s_setprio), build-time knobs for tools/ab_bench.py
+#ifndef SCG_PRIO_P
+#define SCG_PRIO_P 2          // env waves during phase P
+#endif
+#ifndef SCG_PRIO_HELP
+#define SCG_PRIO_HELP 0       // helper waves during phase P
+#endif
+#ifndef SCG_PRIO_LIST
+#define SCG_PRIO_LIST 1       // list waves (0..3) after phase P
+#endif
 
 #ifdef SCG_STAMPS
 #define SCG_STAMP(SEC)                                                                   \
@@ -97,6 +109,28 @@ template <int M>
 __device__ __forceinline__ int sel5(const int (&v)[M], int a) {          // v[a], a < 5, without a dynamically indexed array
     return a == 0 ? v[0] : a == 1 ? v[1] : a == 2 ? v[2] : a == 3 ? v[3] : v[4];
 }
+
+// Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
+// the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
+// 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
+// Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
+// imaginary-part column at 8 h + 4 + i.
+// Every phase derives them afresh from an opaque copy of the lane id: kept live from the top of the kernel, these dozen
+// values (and the per-lane LDS addresses made from them) were what the register allocator spilled to scratch at every
+// phase boundary — 1024 threads x 256 workgroups going to memory together, on the critical path (round 4 stamps).
+#define SCG_LANE_ROLES()                                                                                          \
+    int lane_r = lane;                                                                                            \
+    asm volatile("" : "+v"(lane_r));                                                                              \
+    const int n16 = lane_r & 15, g = lane_r >> 4;                                                                 \
+    const int bi = lane_r & 7, cp = lane_r >> 3;                                                                  \
+    const int bcol = 8 * (bi >> 2) + (bi & 3);               /* builder: real-part column of item bi */          \
+    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);        /* operand lane: item of column n16 within the block */ \
+    const bool out_lane = (g == 0) && !(n16 & 4);            /* lanes that hold an item's finished sums */       \
+    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     /* this wave's private tables */  \
+    const float *ab_lane = abq + n16 * AS + 4 * g;                                                                \
+    const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane_r;                                                  \
+    const float *w8 = s_W + W_TAIL + lane_r;                                                                      \
+    (void)bi; (void)cp; (void)bcol; (void)ocol_item; (void)out_lane; (void)ab_lane; (void)w4; (void)w8; (void)n16; (void)g
 
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
@@ -141,22 +175,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     }
     block_lds_sync();
 
-    // Lane roles. As an MFMA operand lane (16x16x4): n16 = lane & 15 is the tile row (A) / column (B, C, D), g = lane >> 4
-    // the k index (A, B) / the row group (C, D: rows 4 g + v). As a table builder: bi = lane & 7 is the item of an
-    // 8-item column block, cp = lane >> 3 the second index (c2 / c4; lanes with cp >= 6 idle).
-    // Columns of an 8-item block: item j = 4 h + i  (h = 0, 1; i = 0..3) has its real-part column at 8 h + i and its
-    // imaginary-part column at 8 h + 4 + i.
-    const int n16 = lane & 15, g = lane >> 4;
-    const int bi = lane & 7, cp = lane >> 3;
-    const int bcol = 8 * (bi >> 2) + (bi & 3);               // builder: real-part column of item bi
-    const int ocol_item = 4 * (n16 >> 3) + (n16 & 3);         // operand lane: item of column n16 within the block
-    const bool out_lane = (g == 0) && !(n16 & 4);             // lanes that hold an item's finished sums
-    float *cdk = s_R + R_TAB + wave * E_TAB_FLOATS, *abq = cdk + 36 * 16;     // this wave's private tables
-    const float *ab_lane = abq + n16 * AS + 4 * g;
-
     // private tables of one 8-item column block from the builder lane's item `it` (already clamped by the caller),
     // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
-    auto build_tables = [&](int it, int sg) {
+    auto build_tables = [&](int it, int sg, int cp, int bcol, float *cdk, float *abq) {
         if (cp < 6) {
             float2 ab[6], cd[6];
             item_entries(s_z1 + (it * 2 + sg) * 4, cp, ab, cd);
@@ -169,10 +190,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     };
 
     // A operands come from the staged W (value function v of the pass at s_W + v W_FLOATS), per row tile two ds_read_b128
-    // (k-blocks 0..3, 4..7) and one ds_read_b32 (k-block 8)
-    const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane;
-    const float *w8 = s_W + W_TAIL + lane;
-
+    // (k-blocks 0..3, 4..7) and one ds_read_b32 (k-block 8): w4 / w8 of SCG_LANE_ROLES
     // The pass's update list (s_ulist: items of value function A sorted by action, block order inside a run) and its geometry;
     // nBa[a] = how many items at the head of run a also update value function B (0 when the pass has none)
     int run_len[NACT], run_off[NACT], nBa[NACT];
@@ -183,49 +201,127 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // tiles that hold action a's rows, for value function A and — while the column block still holds B items — for B on
     // the SAME tables -> s_qsa[v][list position]. The column blocks of all runs are dealt to `nw` waves.
     auto run_u1 = [&](int wv, int nw, int base) {
+        SCG_LANE_ROLES();
 #pragma unroll 1
         for (int a = 0; a < NACT; ++a) {
             const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
             const int cnt = sel5(run_len, a), cntB = sel5(nBa, a), ro = sel5(run_off, a);
             const uint16_t *lst = s_ulist + ro;
             for (int cb = ((wv - base) & (nw - 1)); 8 * cb < cnt; cb += nw) {
-                build_tables(lst[8 * cb + min(bi, cnt - 8 * cb - 1)], 0);
+                build_tables(lst[8 * cb + min(bi, cnt - 8 * cb - 1)], 0, cp, bcol, cdk, abq);
                 wave_lds_sync();
                 float B[9];
 #pragma unroll
                 for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-#pragma unroll 1
-                for (int v = 0; v < 2; ++v) {
-                    const int cv = v ? cntB : cnt;
-                    if (8 * cb >= cv) break;
-                    float qs = 0.0f;
+                // both value functions' three row tiles as independent MFMA chains, interleaved (a column block that still holds
+                // B items runs 6 chains x 9 MFMAs back to back instead of two times 3 dependent ones)
+                auto tiles = [&](auto nv_c) {
+                    constexpr int NV = decltype(nv_c)::value;
+                    f4v c[NV][3];
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) {
-                        const int t = t0 + tt;
-                        const f4v a0 = w4[v * (W_FLOATS / 4) + (t * 2) * 64], a1 = w4[v * (W_FLOATS / 4) + (t * 2 + 1) * 64];
-                        const float a8 = w8[v * W_FLOATS + t * 64];
-                        f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int v = 0; v < NV; ++v) {
 #pragma unroll
-                        for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
-#pragma unroll
-                        for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
-                        const int r0 = 16 * t + 4 * g - 36 * a;             // c12 of the lane's first row, if in [0, 36)
-                        const bool in = r0 >= 0 && r0 < 36;
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * AS + (in ? r0 : 0));
-                        float xq = qs;
-#pragma unroll
-                        for (int vv = 0; vv < 4; ++vv) xq = fmaf(c[vv], ab4[vv], xq);
-                        qs = in ? xq : qs;
+                        for (int tt = 0; tt < 3; ++tt) c[v][tt] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
                     }
-                    float qo[1] = {qs};
-                    item_tree_sum<1>(qo);
-                    if (out_lane && 8 * cb + ocol_item < cv) s_qsa[v * BLOCK_ENVS + ro + 8 * cb + ocol_item] = qo[0];
-                }
+#pragma unroll
+                    for (int hk = 0; hk < 2; ++hk) {
+                        f4v aop[NV][3];
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                            for (int tt = 0; tt < 3; ++tt) aop[v][tt] = w4[v * (W_FLOATS / 4) + ((t0 + tt) * 2 + hk) * 64];
+                        }
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                                for (int tt = 0; tt < 3; ++tt)
+                                    c[v][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[v][tt][kb], B[4 * hk + kb], c[v][tt], 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt)
+                            c[v][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w8[v * W_FLOATS + (t0 + tt) * 64], B[8], c[v][tt], 0, 0, 0);
+                    }
+                    float qo[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        float qs = 0.0f;
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) {
+                            const int r0 = 16 * (t0 + tt) + 4 * g - 36 * a;     // c12 of the lane's first row, if in [0, 36)
+                            const bool in = r0 >= 0 && r0 < 36;
+                            const f4v ab4 = *reinterpret_cast<const f4v *>(abq + n16 * AS + (in ? r0 : 0));
+                            float xq = qs;
+#pragma unroll
+                            for (int vv = 0; vv < 4; ++vv) xq = fmaf(c[v][tt][vv], ab4[vv], xq);
+                            qs = in ? xq : qs;
+                        }
+                        qo[v] = qs;
+                    }
+                    item_tree_sum<NV>(qo);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int cv = v ? cntB : cnt;
+                        if (out_lane && 8 * cb + ocol_item < cv) s_qsa[v * BLOCK_ENVS + ro + 8 * cb + ocol_item] = qo[v];
+                    }
+                };
+                if (8 * cb < cntB) tiles(std::integral_constant<int, 2>{});
+                else tiles(std::integral_constant<int, 1>{});
                 wave_lds_sync();
             }
             base += (cnt + 7) >> 3;
         }
+    };
+    // Q(sigma, .) of the 8 items whose tables sit in this wave's private area, for the value function staged at float offset
+    // `wofs` of region W (SPEC §3.1): T = W (180 x 36) x [Re CD | Im CD] on the matrix pipe — rows 16 t + 4 g + v -> action
+    // rho / 36, c12 = rho % 36; a lane's four rows never straddle actions — then the fold with the AB factors and the butterfly.
+    // The twelve row tiles are taken in two halves of six (MFMAs, then the fold of those six accumulators into the per-action
+    // chains, tile order kept): 24 accumulator registers instead of 48 at the kernel's register peak. The finished sums are in
+    // the lanes with out_lane.
+    auto contract = [&](int wofs, const float (&B)[9], float (&qo)[NACT], int n16, int g, const f4v *w4, const float *w8, const float *ab_lane) {
+        float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f4v acc[6];
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt) {
+                const int t = 6 * hh + tt;
+                const f4v a0 = w4[wofs / 4 + (t * 2) * 64], a1 = w4[wofs / 4 + (t * 2 + 1) * 64];
+                const float a8 = w8[wofs + t * 64];
+                f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt) {
+                const int t = 6 * hh + tt;
+                const int Ct = (16 * t) % 36, At = (16 * t) / 36;
+                if (Ct + 12 < 36) {                          // the tile's 16 rows belong to one action
+                    const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + Ct);
+#pragma unroll
+                    for (int vv = 0; vv < 4; ++vv) q[At] = fmaf(acc[tt][vv], ab4[vv], q[At]);
+                } else {                                     // row groups g >= (36 - Ct) / 4 belong to the next action
+                    const bool wrap = 4 * g >= 36 - Ct;
+                    const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + (wrap ? Ct - 36 : Ct));
+                    float xq = wrap ? q[At + 1] : q[At];
+#pragma unroll
+                    for (int vv = 0; vv < 4; ++vv) xq = fmaf(acc[tt][vv], ab4[vv], xq);
+                    q[At] = wrap ? q[At] : xq;
+                    q[At + 1] = wrap ? xq : q[At + 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) qo[a] = q[a];
+        item_tree_sum<NACT>(qo);
     };
     // W_k -> region W (+ dstf floats) in A-operand order (12 row tiles of the 180 x 36 matrix; entry (tile t, k-block kb,
     // lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 zero; per tile and lane the k-blocks 0..3 and 4..7 form two
@@ -292,7 +388,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
 
     // ------------------------------------------------------------------ phase P
-    if (helpers && wave < P_WAVES) __builtin_amdgcn_s_setprio(2);   // phase P is the critical path
+    if (helpers) { if (wave < P_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_P); else if (wave >= HELPER0) __builtin_amdgcn_s_setprio(SCG_PRIO_HELP); }
     if (wave < P_WAVES) {                             // one lane per env on P_WAVES full waves
         const int i = tid;
         const bool valid = i < nb;
@@ -301,6 +397,22 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             uint32_t u[4] = {0u, 0u, 0u, 0u};
             int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
             float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
+            float qc[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (valid) {
+                // entry state first: the helper waves can start on it (Z_d^1, the block's option, W staging) while the action is drawn
+                // (all of the env's gathers are issued together: one memory round trip behind the perm lookup)
+                sx = A.x[e]; sy = A.y[e]; svx = A.vx[e]; svy = A.vy[e];
+#pragma unroll
+                for (int aa = 0; aa < NACT; ++aa) qc[aa] = A.qcache[(size_t)aa * N + e];
+                ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];
+                s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
+                s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
+                s_ot[i] = (uint8_t)o;
+            } else {
+                s_ot[i] = 255;
+            }
+            lds_arrive(&s_misc[M_C_PUBS], 64);
+            SCG_STAMP(17);                                        // P: perm + state gathers
             if (valid) {
                 // act (SPEC §2, §4.3)
                 const uint64_t gid = (uint64_t)(A.env_base + e);
@@ -309,26 +421,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 const bool explore = (float)(u[0] >> 8) * 0x1p-24f < A.epsilon;
                 const int a_rand = (int)__umulhi(u[1], 5u);
                 int a_greedy = 0;
-                float best = A.qcache[e];
+                float best = qc[0];
 #pragma unroll
                 for (int aa = 1; aa < NACT; ++aa) {
-                    const float q = A.qcache[(size_t)aa * N + e];
-                    if (q > best) { best = q; a_greedy = aa; }
+                    if (qc[aa] > best) { best = qc[aa]; a_greedy = aa; }
                 }
                 a = explore ? a_rand : a_greedy;
-                SCG_STAMP(16);                                        // P: perm + qcache gathers, Philox, action
-                sx = A.x[e]; sy = A.y[e]; svx = A.vx[e]; svy = A.vy[e];
-                ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];
-                s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
-                s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
-                s_a[i] = (uint8_t)a; s_ot[i] = (uint8_t)o;
+                s_a[i] = (uint8_t)a;
             } else {
-                s_a[i] = 0; s_ot[i] = 255;
+                s_a[i] = 0;
             }
-            if (helpers) lds_arrive(&s_misc[M_C_PUB], 64);                        // state, action and option id of this wave's envs are out
+            SCG_STAMP(16);                                        // P: qcache gathers, Philox, action
+            lds_arrive(&s_misc[M_C_PUB], 64);                                     // state, action and option id of this wave's envs are out
             // physics (SPEC §1.3), the whole wave together
             bool goal;
-            SCG_STAMP(17);                                        // P: state gathers
             // the envs' own wave settles free flight and lists the (env, candidate edge) pairs of the others in groups of 64;
             // the groups of ALL env waves are then dealt to waves 0..P_POOL-1
             bool par;
@@ -479,8 +585,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index
         constexpr int NHT = N_HELP * 64;
         stage_w(A.W, 0, ht, NHT);
-        lds_await(&s_misc[M_C_PUB], 64 * P_WAVES);                                     // the P waves have published s, a and the option ids
+        lds_await(&s_misc[M_C_PUBS], 64 * P_WAVES);                                    // the P waves have published s and the option ids
         decide_b();
+        if (hw == 0 && lane == 0) { s_misc[M_KB] = kB; s_misc[M_MB] = mB; }
         if (kB >= 1) stage_w(A.W + (size_t)kB * NACT * NF, W_FLOATS, ht, NHT);
         for (int u = ht; u < BLOCK_ENVS * 2; u += NHT) {                               // Z_d^1 of the entry states, two variables per thread
             const int i = u & (BLOCK_ENVS - 1), h = u / BLOCK_ENVS;
@@ -492,6 +599,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         // the root's update list (every env, one run per action, block order inside a run): each helper wave derives the
         // run geometry itself from ballots; helper wave 0 writes the list
+        lds_await(&s_misc[M_C_PUB], 64 * P_WAVES);                                     // ... and the actions
         {
             uint64_t mk[P_WAVES][NACT];
             int at[P_WAVES];
@@ -531,7 +639,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
     }
-    if (helpers) { if (wave < LIST_WAVES) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    else if (MODE == MODE_FUSED && wave == HELPER0) {      // acting-only steps: this wave still settles the block's option
+        lds_await(&s_misc[M_C_PUBS], 64 * P_WAVES);
+        decide_b();
+        if (lane == 0) { s_misc[M_KB] = kB; s_misc[M_MB] = mB; }
+    }
+    if (helpers) { if (wave < LIST_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_LIST); else __builtin_amdgcn_s_setprio(0); }
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
@@ -543,8 +656,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             s_z1[(i * 2 + sg) * 4 + d] = sincospi_cs(d < 2 ? sv : fmaf(sv, 0.25f, 0.5f));
         }
     }
-    if (!(helpers && wave >= HELPER0)) decide_b();          // (the helper waves know it already)
-    if (A.k_hi < 0) { kB = -1; mB = 0; }
+    if (MODE == MODE_FUSED && A.k_hi >= 0) {                // the block's option, settled by wave HELPER0 before the barrier
+        kB = __builtin_amdgcn_readfirstlane(s_misc[M_KB]); mB = __builtin_amdgcn_readfirstlane(s_misc[M_MB]);
+    } else { kB = -1; mB = 0; }
 
     // ------------------------------------------------------------------ phase TD (SPEC §3.1, §5) on the matrix pipe
     const unsigned present = (MODE == MODE_FUSED) ? (unsigned)__builtin_amdgcn_readfirstlane(s_misc[M_PRESENT]) : ~0u;
@@ -557,7 +671,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     if (MODE == MODE_FUSED && tid < A.n_vf && A.cnts && tid != 0 && tid != kB && !((single >> tid) & 1u))
         A.cnts[(size_t)b * A.n_vf + tid] = 0;               // value functions without a pass here leave no slab
     const int n_pass0 = A.k_hi >= A.k_lo ? 1 : 0;
+    const int tid_k = tid, lane_k = lane;
     for (int pass = 0; pass < n_pass0 + MAX_VF; ++pass) {
+        // Opaque copies of the thread and lane ids for the pass: every per-lane address of the pass body is loop-invariant, and
+        // hoisted out of the pass loop they all stay live across it — the register allocator then spills them to scratch.
+        int tid_p = tid_k, lane_p = lane_k;
+        asm volatile("" : "+v"(tid_p), "+v"(lane_p));
+        const int tid = tid_p, lane = lane_p;
         int kA, kBp;                                        // value functions of this pass (kBp < 0: none)
         bool dense;                                         // E over position groups (pass 0) or over the compacted eval list
         if (pass == 0) {
@@ -568,7 +688,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             kA = __builtin_ctz(single); single &= single - 1; kBp = -1; dense = false;
         }
         const bool u1_done = helpers && pass == 0;          // the helper waves ran U1 and built the list under phase P
+#ifdef SCG_PASS0_BARRIER
         block_lds_sync();
+#else
+        if (pass > 0) block_lds_sync();                     // (pass 0 starts behind the barrier that ends phase P)
+#endif
         SCG_STAMP(pass == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
         // ---- per-env flags of the pass (SPEC §5): ev bit v = the env needs Q_v(s_next, .) (bootstrap target and/or next
         // action); update items of A (all of them in pass 0 of a fused step: the root updates on every env) with their action
@@ -674,6 +798,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         const int npg = dense ? (nb + 7) >> 3 : 0;
         const int n_units = npg + ((n_cmp + 7) >> 3);
         if (n_units + nupd == 0) continue;
+        {
+        SCG_LANE_ROLES();
         for (int u = wave; u < n_units; u += WAVES) {
             const bool du = u < npg;
             const int base = du ? 8 * u : 8 * (u - npg);
@@ -682,7 +808,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             if (!fl) continue;
             {
                 const int j = min(bi, cnt - 1);
-                build_tables(du ? base + j : (int)s_elist[base + j], 1);
+                build_tables(du ? base + j : (int)s_elist[base + j], 1, cp, bcol, cdk, abq);
             }
             wave_lds_sync();
             float B[9];
@@ -693,39 +819,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll 1
             for (int v = 0; v < 2; ++v) {
                 if (!((fl >> v) & 1u)) continue;
-                f4v acc[12];
-#pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const f4v a0 = w4[v * (W_FLOATS / 4) + (t * 2) * 64], a1 = w4[v * (W_FLOATS / 4) + (t * 2 + 1) * 64];
-                    const float a8 = w8[v * W_FLOATS + t * 64];
-                    f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
-                }
-                // rows 16 t + 4 g + v -> action rho / 36, c12 = rho % 36; a lane's four rows never straddle actions
-                float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int t = 0; t < 12; ++t) {
-                    const int Ct = (16 * t) % 36, At = (16 * t) / 36;
-                    if (Ct + 12 < 36) {                          // the tile's 16 rows belong to one action
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + Ct);
-#pragma unroll
-                        for (int vv = 0; vv < 4; ++vv) q[At] = fmaf(acc[t][vv], ab4[vv], q[At]);
-                    } else {                                     // row groups g >= (36 - Ct) / 4 belong to the next action
-                        const bool wrap = 4 * g >= 36 - Ct;
-                        const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + (wrap ? Ct - 36 : Ct));
-                        float xq = wrap ? q[At + 1] : q[At];
-#pragma unroll
-                        for (int vv = 0; vv < 4; ++vv) xq = fmaf(acc[t][vv], ab4[vv], xq);
-                        q[At] = wrap ? q[At] : xq;
-                        q[At + 1] = wrap ? xq : q[At + 1];
-                    }
-                }
-                float qo[NACT] = {q[0], q[1], q[2], q[3], q[4]};
-                item_tree_sum<NACT>(qo);
+                float qo[NACT];
+                contract(v * W_FLOATS, B, qo, n16, g, w4, w8, ab_lane);
                 if (out_lane && have && ((s_ev[il] >> v) & 1)) {
                     const int kv = v ? kBp : kA;
                     if (s_on[il] == kv) {
@@ -746,6 +841,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
             wave_lds_sync();
         }
+        }
         SCG_STAMP(pass == 0 ? 3 : 10);   // E (wave 0's share)
         // ---- U1 (pass 0 of a learning step: ran under phase P on the helper waves)
         if (MODE != MODE_QVAL && nupd > 0 && !u1_done) run_u1(wave, WAVES, n_units);   // dealt on behind E's blocks
@@ -754,39 +850,62 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
         SCG_STAMP(pass == 0 ? 7 : 14);   // wait for the other waves
 
-        // ---- U2: the block partials (SPEC §5). Padded slots: every action run of A's list is padded with null items to a
-        // multiple of 4, run a occupying slots [off4[a], off4[a + 1]). Chunks of U2_CH = 144 slots (kap = 2 slot + part):
-        //   build  CDT[c34][kap] = CD, PT_A[c12][kap] = delta_A ABsel and, for the first len4B[a] slots of run a,
-        //          PT_B[c12][kap] = delta_B ABsel (null items: +0); wave w owns slots 9 w .. 9 w + 8
-        //   MFMA   G_v[a] += PT_v x CDT^T, groups of 4 items: one MFMA over their real parts, one over the imaginary parts;
-        //          the 9 output tiles of (v, a) are jobs J = 45 v + 9 a + q dealt to the waves (J mod 16), accumulators stay
-        //          in registers for the whole pass and go straight to the block's slabs
-        int off4[NACT + 1], len4B[NACT];
-        off4[0] = 0;
+        // ---- U2: the block partials (SPEC §5). Every action run of A's list is padded with null items to a multiple of 4
+        // (groups of four items); run a has Ga groups, the first GBa of which also carry items of B. The groups are laid out in
+        // chunks of <= U2_CH = 144 slots: one chunk if everything fits, else two, chunk 0 holding the first ceil(Ga / 2) groups of
+        // EVERY run and chunk 1 the rest (sum_a ceil(Ga / 2) <= 36 groups = 144 slots for the <= 271 padded slots of 256 envs) — so
+        // every wave has half of its products in either chunk (a chunk of consecutive slots held whole runs: the waves of two or
+        // three actions multiplied while the others waited). The chains of SPEC §5 run per action in group order: unchanged.
+        //   build  CDT[c34][kap] = CD, PT_A[c12][kap] = delta_A ABsel and, for B's groups, PT_B[c12][kap] = delta_B ABsel
+        //          (kap = 2 slot + part; null items: +0); wave w owns slots 9 w .. 9 w + 8 of the chunk
+        //   MFMA   G_v[a] += PT_v x CDT^T per group: one MFMA over the four real parts, one over the imaginary parts.
+        //          Wave w < 15 owns the three output tiles (mi = w % 3, ni = 0..2) of action a = w / 3 of BOTH value functions:
+        //          per group one P operand per value function and three C operands feed six (twelve) independent MFMAs;
+        //          accumulators stay in registers for the whole pass and go straight to the block's slabs
+        int lane_u = lane;
+        asm volatile("" : "+v"(lane_u));                    // (lane roles derived afresh: see SCG_LANE_ROLES)
+        const int n16 = lane_u & 15, g = lane_u >> 4;
+        int Ga[NACT], GBa[NACT];
+        int Gtot = 0;
 #pragma unroll
-        for (int a = 0; a < NACT; ++a) { off4[a + 1] = off4[a] + ((run_len[a] + 3) & ~3); len4B[a] = (nBa[a] + 3) & ~3; }
+        for (int a = 0; a < NACT; ++a) { Ga[a] = (run_len[a] + 3) >> 2; GBa[a] = (nBa[a] + 3) >> 2; Gtot += Ga[a]; }
+        const int nch = 4 * Gtot <= U2_CH ? 1 : 2;
         int wave_u = wave;
-        asm volatile("" : "+s"(wave_u));                    // keeps the per-(wave, job) tile geometry inside the pass
-        const int n_jobs = nupdB > 0 ? 2 * NACT * 9 : NACT * 9;
-        constexpr int JOBS = (2 * NACT * 9 + WAVES - 1) / WAVES;      // job slots per wave
-        f4v accU[JOBS];
+        asm volatile("" : "+s"(wave_u));                    // keeps the per-wave tile geometry inside the pass
+        const bool haveB = nupdB > 0;
+        const bool worker = wave_u < 3 * NACT;              // waves 0..14 multiply, wave 15 only builds
+        const int ja = (wave_u * 11) >> 5, jm = wave_u - 3 * ja;              // this wave's action (w / 3) and row tile (w % 3)
+        const int j_GB = sel5(GBa, ja), j_nB = sel5(nBa, ja);
+        f4v accU[2][3];
 #pragma unroll
-        for (int s = 0; s < JOBS; ++s) accU[s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) accU[v][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+        }
         float *ptabA = s_R, *ptabB = s_R + 36 * US, *ctab = s_R + 2 * 36 * US;
         const float *rA = (MODE == MODE_FUSED && kA != 0) ? s_rk : s_r0, *cA = (MODE == MODE_FUSED && kA != 0) ? s_ck : s_c0;
-        const int bi9 = lane % 9, cp9 = lane / 9;           // builder lanes of a chunk: (slot 9 wave + bi9, second index cp9 < 6)
-        for (int ch0 = 0; ch0 < off4[NACT]; ch0 += U2_CH) {
-            if (ch0 > 0) block_lds_sync();                                    // previous chunk's operands consumed
+        const int bi9 = lane_u % 9, cp9 = lane_u / 9;       // builder lanes of a chunk: (slot 9 wave + bi9, second index cp9 < 6)
+        for (int ch = 0; ch < nch; ++ch) {
+            // this chunk's share of every run: groups [gb[a], gb[a] + gc[a]) at slots [co[a], co[a + 1])
+            int gb[NACT], gc[NACT], co[NACT + 1];
+            co[0] = 0;
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) {
+                const int first = nch == 1 ? Ga[a] : (Ga[a] + 1) >> 1;
+                gb[a] = ch == 0 ? 0 : first;
+                gc[a] = ch == 0 ? first : Ga[a] - first;
+                co[a + 1] = co[a] + 4 * gc[a];
+            }
+            if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
             SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
             {
-                const int slot = 9 * wave + bi9, ps = ch0 + slot;
-                if (cp9 < 6 && ps < off4[NACT]) {
+                const int slot = 9 * wave + bi9;
+                if (cp9 < 6 && slot < co[NACT]) {
                     int a_ = 0;
 #pragma unroll
-                    for (int a = 1; a < NACT; ++a) a_ += ps >= off4[a] ? 1 : 0;
-                    const int o4 = a_ == 0 ? off4[0] : a_ == 1 ? off4[1] : a_ == 2 ? off4[2] : a_ == 3 ? off4[3] : off4[4];
-                    const int rl = sel5(run_len, a_), ro = sel5(run_off, a_), nbq = sel5(nBa, a_), l4b = sel5(len4B, a_);
-                    const int j = ps - o4;
+                    for (int a = 1; a < NACT; ++a) a_ += slot >= co[a] ? 1 : 0;
+                    const int rl = sel5(run_len, a_), ro = sel5(run_off, a_), nbq = sel5(nBa, a_), l4b = 4 * sel5(GBa, a_);
+                    const int j = 4 * sel5(gb, a_) + slot - sel5(co, a_);     // slot of the padded run
                     float *pdA = ptabA + cp9 * US + 2 * slot, *pdB = ptabB + cp9 * US + 2 * slot, *cdst = ctab + cp9 * US + 2 * slot;
                     if (j < rl) {
                         const int li = ro + j, il = s_ulist[li];
@@ -827,45 +946,59 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             SCG_STAMP(21);                                       // (diagnostic) U2: build
             block_lds_sync();                                    // operands visible
             SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
-#pragma unroll
-            for (int s = 0; s < JOBS; ++s) {
-                const int J = wave_u + WAVES * s;
-                if (J >= n_jobs) continue;
-                const int v = J >= NACT * 9 ? 1 : 0, Jr = J - NACT * 9 * v;
-                const int a = (Jr * 57) >> 9, q = Jr - 9 * a;                  // Jr / 9, Jr % 9 for Jr < 45
-                const int mi = (q * 11) >> 5, ni = q - 3 * mi;                  // q / 3, q % 3
-                const int o4 = sel5(off4, a), len = v ? sel5(len4B, a) : (((sel5(run_len, a)) + 3) & ~3);
-                const int lo = max(o4, ch0), hi = min(o4 + len, ch0 + U2_CH);   // the run's slots in this chunk
-                if (lo >= hi) continue;
-                const float *pa = (v ? ptabB : ptabA) + min(16 * mi + n16, 35) * US + 2 * g + 2 * (lo - ch0);
-                const float *pb = ctab + min(16 * ni + n16, 35) * US + 2 * g + 2 * (lo - ch0);
-                const int ngrp = (hi - lo) >> 2;
-                const int nvalid = v ? sel5(nBa, a) - (lo - o4) : (1 << 30);    // B: items of the run still real from slot lo on
-                for (int gi = 0; gi < ngrp; ++gi) {
-                    const float2 a2 = *reinterpret_cast<const float2 *>(pa + 8 * gi);
-                    float2 b2 = *reinterpret_cast<const float2 *>(pb + 8 * gi);
-                    if (v && 4 * gi + g >= nvalid) b2 = make_float2(0.0f, 0.0f);     // null item of B: both operands +0 (SPEC §5)
-                    accU[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.x, a2.x, accU[s], 0, 0, 0);
-                    accU[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2.y, a2.y, accU[s], 0, 0, 0);
+            if (worker) {
+                const int ngrp = sel5(gc, ja), g0 = sel5(gb, ja), so = sel5(co, ja);      // run ja's groups in this chunk, from group g0, at slot so
+                if (ngrp > 0) {
+                    const int ngrpB = haveB ? min(max(j_GB - g0, 0), ngrp) : 0;          // ... of which B's
+                    const int prow = min(16 * jm + n16, 35) * US + 2 * g + 2 * so;
+                    const float *paA = ptabA + prow, *paB = ptabB + prow;
+                    const float *pb0 = ctab + n16 * US + 2 * g + 2 * so, *pb1 = pb0 + 16 * US,
+                                *pb2 = ctab + min(32 + n16, 35) * US + 2 * g + 2 * so;
+                    const int nvalid = j_nB - 4 * g0;                                    // B items of the run still real from group g0 on
+                    for (int gi = 0; gi < ngrp; ++gi) {
+                        const float2 a2 = *reinterpret_cast<const float2 *>(paA + 8 * gi);
+                        float2 c0 = *reinterpret_cast<const float2 *>(pb0 + 8 * gi), c1 = *reinterpret_cast<const float2 *>(pb1 + 8 * gi),
+                               c2 = *reinterpret_cast<const float2 *>(pb2 + 8 * gi);
+                        accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, a2.x, accU[0][0], 0, 0, 0);
+                        accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, a2.x, accU[0][1], 0, 0, 0);
+                        accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, a2.x, accU[0][2], 0, 0, 0);
+                        accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, a2.y, accU[0][0], 0, 0, 0);
+                        accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, a2.y, accU[0][1], 0, 0, 0);
+                        accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, a2.y, accU[0][2], 0, 0, 0);
+                        if (gi < ngrpB) {
+                            const float2 b2 = *reinterpret_cast<const float2 *>(paB + 8 * gi);
+                            if (4 * gi + 4 > nvalid && 4 * gi + g >= nvalid) {            // null item of B: both operands +0 (SPEC §5)
+                                c0 = make_float2(0.0f, 0.0f); c1 = c0; c2 = c0;
+                            }
+                            accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, b2.x, accU[1][0], 0, 0, 0);
+                            accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, b2.x, accU[1][1], 0, 0, 0);
+                            accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, b2.x, accU[1][2], 0, 0, 0);
+                            accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, b2.y, accU[1][0], 0, 0, 0);
+                            accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b2.y, accU[1][1], 0, 0, 0);
+                            accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, b2.y, accU[1][2], 0, 0, 0);
+                        }
+                    }
                 }
             }
+            SCG_STAMP(9);                                        // (diagnostic) U2: this wave's own products of the chunk
         }
         SCG_STAMP(pass == 0 ? 6 : 13);   // U2
         // the block partials straight from the accumulators (zeros for an empty run). The tiles were accumulated
         // TRANSPOSED (A operand = CDT rows, B operand = PT rows; fma(a, b, c) = fma(b, a, c)), so register v of lane (n16, g)
         // of tile (mi, ni) is G[a][c12 = 16 mi + n16][c34 = 16 ni + 4 g + v]: one 16-byte store per lane and tile
         if (!s_misc[M_FAIL]) {
+            if (worker) {
 #pragma unroll
-            for (int s = 0; s < JOBS; ++s) {
-                const int J = wave_u + WAVES * s;
-                if (J >= n_jobs) continue;
-                const int v = J >= NACT * 9 ? 1 : 0, Jr = J - NACT * 9 * v;
-                const int a = (Jr * 57) >> 9, q = Jr - 9 * a;
-                const int mi = (q * 11) >> 5, ni = q - 3 * mi;
-                const int kv = v ? kBp : kA;
-                const bool okl = (mi < 2 || n16 < 4) && (ni < 2 || g == 0);
-                float *slab_lane = A.slabs + ((size_t)b * A.n_vf + kv) * NACT * NF + n16 * 36 + 4 * g;
-                if (okl) store_wt(slab_lane + a * NF + (16 * mi) * 36 + 16 * ni, accU[s]);
+                for (int v = 0; v < 2; ++v) {
+                    if (v == 1 && !haveB) break;
+                    const int kv = v ? kBp : kA;
+                    float *slab_lane = A.slabs + ((size_t)b * A.n_vf + kv) * NACT * NF + ja * NF + (16 * jm + n16) * 36 + 4 * g;
+#pragma unroll
+                    for (int ni = 0; ni < 3; ++ni) {
+                        const bool okl = (jm < 2 || n16 < 4) && (ni < 2 || g == 0);
+                        if (okl) store_wt(slab_lane + 16 * ni, accU[v][ni]);
+                    }
+                }
             }
         } else if (tid == 0 && A.cnts) {
             A.cnts[(size_t)b * A.n_vf + kA] = 0;
@@ -873,96 +1006,84 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(15);                // slab stores issued
     }
-    // ------------------------------------------------------------------ evaluation-only value functions, on the vector pipe
-    // Q_k(s_next, .) of the few envs entering an option nobody in this workgroup runs. The (value function, env) pairs are
-    // enumerated in a fixed order by every wave and dealt round-robin; a wave evaluates its pair alone, with W_k read
-    // straight from global memory (one 36-float row per lane and round) — no staging, no lists, no workgroup barrier. The
-    // arithmetic is SPEC §3.1 operation for operation (the MFMA is the same fmaf chain), so the result is bit-identical to
-    // what a pass would have produced.
-    if (MODE == MODE_FUSED && eval_only && A.k_hi >= 0) {
-        block_lds_sync();                                   // region R is free again
-        SCG_STAMP(26);
-        float2 *t_ab = reinterpret_cast<float2 *>(cdk), *t_cd = t_ab + 36, *t_T = t_cd + 36;      // this wave's table area: 36 + 36 + 180 float2
-        int pair = 0;
-        for (int k = 1; k < A.n_vf; ++k) {
-            if (!((eval_only >> k) & 1u)) continue;
-            const float *Wk = A.W + (size_t)k * NACT * NF;
-            for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
-                const int ii = 64 * h + lane;
-                uint64_t m = __ballot(ii < nb && s_on[ii] == k);
-                while (m) {
-                    const int il = 64 * h + (int)__builtin_ctzll(m);
-                    m &= m - 1;
-                    if ((pair++ & (WAVES - 1)) != wave) continue;
-                    // tables of s_next: lane c < 36 owns AB[c] and CD[c] (c = 6 hi + lo)
-                    if (lane < 36) {
-                        const float4 *zp = reinterpret_cast<const float4 *>(s_z1 + (il * 2 + 1) * 4);
-                        const float4 za = zp[0], zc = zp[1];
-                        const int hi = (lane * 43) >> 8, lo = lane - 6 * hi;                  // lane / 6, lane % 6 for lane < 36
-                        float2 ab = zpow_sel(make_float2(za.z, za.w), lo), cd = zpow_sel(make_float2(zc.z, zc.w), lo);
+    // ------------------------------------------------------------------ evaluation-only value functions
+    // Q_k(s_next, .) of the envs ENTERING an option nobody in this block runs (about 14 (value function, env) pairs per block on
+    // the bench workload, over 2-4 value functions). Behind the passes region R is free: the weights of up to EO_SLOTS such
+    // value functions are staged side by side (one coalesced read each), then one wave per slot — waves 0, 4, 8, 12: one per
+    // SIMD — compacts its value function's envs eight at a time and evaluates them as ordinary E units on the matrix pipe:
+    // bit-identical to a pass by construction, one barrier pair per round of EO_SLOTS value functions. (Rounds 2-3 evaluated
+    // every pair on the vector pipe with W_k rows read per lane from global memory: with one workgroup per CU those strided
+    // 16-byte gathers — 27 KB per pair through the CU's one texture path — were 19k cycles of nobody's time but this wave's.)
+    if (MODE == MODE_FUSED && eval_only) {
+        constexpr int EO_SLOTS = 4;
+        static_assert(EO_SLOTS * (W_FLOATS + E_TAB_FLOATS) <= R_FLOATS && EO_SLOTS * 4 <= WAVES, "slots fit region R");
+        unsigned todo = eval_only;
+        while (todo) {
+            int tid_e = tid_k, lane_e = lane_k;             // (opaque per round, as in the pass loop: no hoisting, no spills)
+            asm volatile("" : "+v"(tid_e), "+v"(lane_e));
+            const int tid = tid_e, lane = lane_e;
+            int ks[EO_SLOTS];
+            int ns = 0;
 #pragma unroll
-                        for (int c = 1; c < 6; ++c) {                                         // row hi: hi chained products
-                            const float2 abn = cmul(ab, make_float2(za.x, za.y)), cdn = cmul(cd, make_float2(zc.x, zc.y));
-                            if (c <= hi) { ab = abn; cd = cdn; }
-                        }
-                        t_ab[lane] = make_float2(ab.x, -ab.y);
-                        t_cd[lane] = cd;
+            for (int sl = 0; sl < EO_SLOTS; ++sl) {
+                ks[sl] = todo ? __builtin_ctz(todo) : 0;
+                if (todo) { ++ns; todo &= todo - 1; }
+            }
+            block_lds_sync();                               // region R is free (the last U2 chunk / the previous round is consumed)
+            SCG_STAMP(26);
+#pragma unroll
+            for (int sl = 0; sl < EO_SLOTS; ++sl)
+                if (sl < ns) stage_w(A.W + (size_t)ks[sl] * NACT * NF, sl * W_FLOATS, tid, THREADS);
+            block_lds_sync();
+            if ((wave & 3) == 0 && (wave >> 2) < ns) {
+                const int sl = wave >> 2;
+                const int k = sl == 0 ? ks[0] : sl == 1 ? ks[1] : sl == 2 ? ks[2] : ks[3];
+                int lane_r = lane;
+                asm volatile("" : "+v"(lane_r));
+                const int n16 = lane_r & 15, g = lane_r >> 4, bi = lane_r & 7, cp = lane_r >> 3;
+                const int bcol = 8 * (bi >> 2) + (bi & 3), ocol_item = 4 * (n16 >> 3) + (n16 & 3);
+                const bool out_lane = (g == 0) && !(n16 & 4);
+                float *cdk = s_R + EO_SLOTS * W_FLOATS + sl * E_TAB_FLOATS, *abq = cdk + 36 * 16;
+                const float *ab_lane = abq + n16 * AS + 4 * g;
+                const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane_r;
+                const float *w8 = s_W + W_TAIL + lane_r;
+                uint16_t *slot8 = s_elist + 8 * sl;         // the unit's items (positions), written by the lanes that own them
+                uint64_t mk[BLOCK_ENVS / 64];
+                int total = 0;
+#pragma unroll
+                for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
+                    mk[h] = __ballot(64 * h + lane_r < nb && s_on[64 * h + lane_r] == k);
+                    total += __popcll(mk[h]);
+                }
+                const uint64_t below = (1ull << lane_r) - 1ull;
+                for (int u0 = 0; u0 < total; u0 += 8) {
+                    const int cnt = min(8, total - u0);
+                    int before = 0;
+#pragma unroll
+                    for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
+                        const int r = before + __popcll(mk[h] & below) - u0;             // rank of this lane's env among the entering ones
+                        if (((mk[h] >> lane_r) & 1ull) && r >= 0 && r < 8) slot8[r] = (uint16_t)(64 * h + lane_r);
+                        before += __popcll(mk[h]);
                     }
                     wave_lds_sync();
-                    // T[row][re | im], row = 36 a + c12: the fmaf chain over c34 = 9 g + kb (kb outer, g inner)
-#pragma unroll 1
-                    for (int r0 = 0; r0 < 192; r0 += 64) {
-                        const int row = r0 + lane;
-                        if (row < 180) {
-                            const float4 *wr = reinterpret_cast<const float4 *>(Wk + row * 36);
-                            float wv[36];
-#pragma unroll
-                            for (int q4 = 0; q4 < 9; ++q4) {
-                                const float4 w = wr[q4];
-                                wv[4 * q4] = w.x; wv[4 * q4 + 1] = w.y; wv[4 * q4 + 2] = w.z; wv[4 * q4 + 3] = w.w;
-                            }
-                            float tre = 0.0f, tim = 0.0f;
-#pragma unroll
-                            for (int kb = 0; kb < 9; ++kb) {
-#pragma unroll
-                                for (int gg = 0; gg < 4; ++gg) {
-                                    const float2 cdv = t_cd[9 * gg + kb];
-                                    tre = fmaf(wv[9 * gg + kb], cdv.x, tre);
-                                    tim = fmaf(wv[9 * gg + kb], cdv.y, tim);
-                                }
-                            }
-                            t_T[row] = make_float2(tre, tim);
-                        }
-                    }
+                    build_tables((int)slot8[min(bi, cnt - 1)], 1, cp, bcol, cdk, abq);
+                    const int il = slot8[min(ocol_item, cnt - 1)];
                     wave_lds_sync();
-                    // q[a][g][part]: lane = 8 a + 2 g + part chains over its nine c12 in increasing order, then the tree
-                    float qv = 0.0f;
-                    {
-                        const int a = min(lane >> 3, NACT - 1), gq = (lane >> 1) & 3, part = lane & 1;
-                        // rows 36 a + c12 of group gq: c12 = 4 i + v with ((36 a) / 4 + i) % 4 == gq  ->  i = (gq - 9 a) & 3, + 4, + 8
-                        const int i0 = (gq - 9 * a) & 3;
+                    float B[9];
 #pragma unroll
-                        for (int ii3 = 0; ii3 < 3; ++ii3) {
-                            const int i = i0 + 4 * ii3;                                  // i = 0..8: quad of rows 4 i .. 4 i + 3
-                            if (i < 9) {
-#pragma unroll
-                                for (int v = 0; v < 4; ++v) {
-                                    const float2 tv = t_T[36 * a + 4 * i + v], av = t_ab[4 * i + v];
-                                    qv = fmaf(part ? tv.y : tv.x, part ? av.y : av.x, qv);
-                                }
-                            }
-                        }
+                    for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
+                    float qo[NACT];
+                    contract(sl * W_FLOATS, B, qo, n16, g, w4, w8, ab_lane);
+                    if (out_lane && ocol_item < cnt) {      // into the env's result line (orec[2].xyzw, orec[3].x); commit_row writes qcache
+                        float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                        orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                        orec[3].x = qo[4];
                     }
-                    qv = qv + __shfl_xor(qv, 1, 64);                      // u_g = q_re + q_im
-                    qv = qv + __shfl_xor(qv, 2, 64);                      // u_0 + u_1 | u_2 + u_3
-                    qv = qv + __shfl_xor(qv, 4, 64);                      // (u_0 + u_1) + (u_2 + u_3)
-                    if (lane < 8 * NACT && (lane & 7) == 0)               // into the env's result line (orec[2].xyzw, orec[3].x)
-                        reinterpret_cast<float *>(A.outrec + (size_t)(e0 + il) * 4)[8 + (lane >> 3)] = qv;
                     wave_lds_sync();
                 }
             }
+            SCG_STAMP(27);
         }
-        SCG_STAMP(27);
     }
     if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)
         block_lds_sync();

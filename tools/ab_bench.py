@@ -13,7 +13,7 @@ for r in range(a.rounds):
     for l in a.libs:
         env = dict(os.environ, SCG_LIB=os.path.abspath(l))
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", str(a.steps), "--warmup", "50",
-                              "--no-cpu-baseline"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+                              "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         d = json.loads(out)
         row = (d["value"] / 1e6, d["ms_per_step"] * 1e3, d["roofline"]["kernel_ms"] * 1e3)
         res[l].append(row)

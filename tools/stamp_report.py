@@ -25,13 +25,13 @@ for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
 out = np.zeros((nblk, 32), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
-names = ["phase P (rest: trace, hist, barrier)", "root: phase Z + lists + W staging", "P: physics, pooled (env, edge) pair groups + hand-offs", "root: E (eval)", "root: U1 (Q(s,a))",
-         "root: barrier at pass start", "root: U2 (accumulate)", "root: wait before U2", "opt: lists + W staging", "opt: A operands -> registers",
-         "opt: E (eval)", "opt: U1 (Q(s,a))", "opt: barrier at pass start", "opt: U2 (accumulate)", "opt: wait before U2", "slab stores",
-         "P: perm, qcache, Philox, action", "P: state gathers", "P: physics, own part (refine, free flight, pair lists)", "P: bookkeeping, options, result line",
-         "U2: MFMAs of a chunk + wait, but the last", "U2: build", "U2: wait for the other waves' build", "lists: flags + ballots", "lists: W staging", "lists: barrier behind the staging", "eval-only: wait", "eval-only: VALU evaluation", "(helper wave 4: kernel start -> its U1 done; not part of the total)"] + ["-"] * 3
+names = ["phase P (rest: trace, hist, barrier)", "pass 0: phase Z + flags + (W staging)", "P: physics, pooled (env, edge) pair groups + hand-offs", "pass 0: E (eval, both VFs)", "pass 0: U1 (only when no helper ran it)",
+         "pass 0: Z + lists until the pass stamp", "pass 0: U2 (last chunk: wait)", "pass 0: wait before U2", "single passes: lists + W staging", "U2: own products of a chunk",
+         "single passes: E", "single passes: U1", "single passes: barrier at pass start", "single passes: U2 (last chunk)", "single passes: wait before U2", "slab stores",
+         "P: qcache gathers, Philox, action", "P: perm + state gathers", "P: physics, own part (refine, free flight, pair lists)", "P: bookkeeping, options, result line",
+         "U2: prologue / wait for the previous chunk's products", "U2: build", "U2: wait for the other waves' build", "flags + ballots", "W staging (when not under P)", "barrier behind the staging", "eval-only: wait for region R", "eval-only: staging + units on the matrix pipe", "(helper wave 8: kernel start -> its U1 done; not part of the total)", "(count: eval-only pairs wave 0 took)", "(count: eval-only pairs in the block)", "-"]
 mean = out.astype(np.float64).mean(0) / args.steps
-tot = mean.sum() - mean[28]
+tot = mean.sum() - mean[28] - mean[29] - mean[30]
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
 for nme, v in zip(names, mean): print(f"  {nme:36s} {v:10.0f}  {100*v/tot:5.1f} %")
 per_block = out.astype(np.float64).sum(1) / args.steps
