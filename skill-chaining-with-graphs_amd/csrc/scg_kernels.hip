@@ -1123,8 +1123,8 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         return st;
     }
 #ifdef SCG_STAMPS
-    if (hipMalloc(&c->d_stamps, (size_t)c->nblk * 32 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 32 * sizeof(unsigned long long));
+    if (hipMalloc(&c->d_stamps, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long));
 #endif
     c->parents = 0;
     for (int k = 1; k < MAX_VF; ++k) c->parents |= (uint32_t)(k - 1) << (3 * k);      // chain: 1 -> goal, k -> k-1
@@ -1344,8 +1344,8 @@ int scg_invalidate_order(scg_ctx *c) {
 #ifdef SCG_STAMPS
 extern "C" int scg_diag_stamps(scg_ctx *c, unsigned long long *host_out /*[nblk][16]*/, int32_t reset) {
     if (!c || !c->d_stamps) return SCG_ERR_STATE;
-    if (host_out && hipMemcpy(host_out, c->d_stamps, (size_t)c->nblk * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return SCG_ERR_HIP;
-    if (reset) (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * 32 * sizeof(unsigned long long));
+    if (host_out && hipMemcpy(host_out, c->d_stamps, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return SCG_ERR_HIP;
+    if (reset) (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long));
     return SCG_OK;
 }
 #endif

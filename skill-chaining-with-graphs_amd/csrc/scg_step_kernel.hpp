@@ -25,10 +25,14 @@
 #pragma once
 
 constexpr int P_WAVES = BLOCK_ENVS / 64;      // phase P: one lane per env on full waves
-constexpr int HELPER0 = WAVES / 2;            // waves HELPER0.. work under phase P (learning steps)
+constexpr int LIST0 = P_WAVES;                // waves LIST0 .. LIST0 + LIST_WAVES - 1 build the passes' flags and lists
+#ifndef SCG_HELPER0
+#define SCG_HELPER0 7          // (7 pool + 9 helper waves measured +1.2 % over 8 + 8, 6 + 10 +0.6 %)
+#endif
+constexpr int HELPER0 = SCG_HELPER0;          // waves HELPER0.. work under phase P (learning steps)
 constexpr int N_HELP = WAVES - HELPER0;
 constexpr int P_POOL = HELPER0;               // waves 0..P_POOL-1 share the physics' (env, edge) pair groups
-static_assert((N_HELP & (N_HELP - 1)) == 0 && (WAVES & (WAVES - 1)) == 0, "column blocks are dealt with a power-of-two mask");
+static_assert(HELPER0 >= P_WAVES && N_HELP >= 8 && N_HELP * 64 * 3 >= 12 * 2 * 64, "stage_w by the helper waves: at most three float4 per thread");
 // LDS map of the step kernel (bytes): one workgroup per CU, the whole 160 KB.
 constexpr int OFF_RC = 0;                                      // float r0,c0,ro,co (per env), rk,ck (per env, single passes) [B]
 constexpr int OFF_INT = OFF_RC + 6 * BLOCK_ENVS * 4;           // uint8 a, ot, on, gs, ia, ev [B]
@@ -56,8 +60,9 @@ constexpr int OFF_EFLAG = OFF_QSA + 2 * BLOCK_ENVS * 4;        // uint8 eflag[B 
 constexpr int OFF_CLF = OFF_EFLAG + 64;                        // float clf[6][8]
 constexpr int OFF_MISC = OFF_CLF + MAX_VF * CLF_STRIDE * 4;    // int misc[128]
 #ifdef SCG_STAMPS
-constexpr int OFF_STAMP = OFF_MISC + 512;                      // unsigned stamp[32] (diagnostic build)
-constexpr int LDS_BYTES = OFF_STAMP + 128;
+constexpr int STAMP_SLOTS = 48;                                // 32 sections of wave 0 + the E phase of every wave
+constexpr int OFF_STAMP = OFF_MISC + 512;                      // unsigned stamp[STAMP_SLOTS] (diagnostic build)
+constexpr int LDS_BYTES = OFF_STAMP + STAMP_SLOTS * 4;
 #else
 constexpr int LDS_BYTES = OFF_MISC + 512;
 #endif
@@ -82,6 +87,19 @@ static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 // wave priorities (s_setprio), build-time knobs for tools/ab_bench.py
+// Evaluation-only value functions (envs ENTERING an option nobody in the block runs), three builds for tools/ab_bench.py:
+//   default       extra E units of pass 0, A operands straight from W_k in memory (contract_g)
+//   SCG_EO_MFMA   behind the passes: up to four W_k staged side by side, one wave per slot, E units from LDS
+//   SCG_EO_VALU   on the vector pipe behind each wave's E units (rounds 2-3), [SCG_EO_VALU_COALESCED: rows through LDS]
+#if !defined(SCG_EO_MFMA) && !defined(SCG_EO_VALU)
+#define SCG_EO_UNITS 1
+#endif
+#ifndef SCG_E_TG
+#define SCG_E_TG 4            // row tiles per operand group of the LDS-fed contraction (12 % SCG_E_TG == 0)
+#endif
+#ifndef SCG_EO_TG
+#define SCG_EO_TG 3           // row tiles whose operands contract_g fetches together (register budget: 9 per tile)
+#endif
 #ifndef SCG_PRIO_P
 #define SCG_PRIO_P 2          // env waves during phase P
 #endif
@@ -164,7 +182,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const int N = A.n;
 #ifdef SCG_STAMPS
     unsigned *s_stamp = reinterpret_cast<unsigned *>(smem + OFF_STAMP);
-    if (tid < 32) s_stamp[tid] = 0;
+    if (tid < STAMP_SLOTS) s_stamp[tid] = 0;
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
             const int cnt = sel5(run_len, a), cntB = sel5(nBa, a), ro = sel5(run_off, a);
             const uint16_t *lst = s_ulist + ro;
-            for (int cb = ((wv - base) & (nw - 1)); 8 * cb < cnt; cb += nw) {
+            for (int cb = (((wv - base) % nw) + nw) % nw; 8 * cb < cnt; cb += nw) {
                 build_tables(lst[8 * cb + min(bi, cnt - 8 * cb - 1)], 0, cp, bcol, cdk, abq);
                 wave_lds_sync();
                 float B[9];
@@ -283,26 +301,33 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // The twelve row tiles are taken in two halves of six (MFMAs, then the fold of those six accumulators into the per-action
     // chains, tile order kept): 24 accumulator registers instead of 48 at the kernel's register peak. The finished sums are in
     // the lanes with out_lane.
-    auto contract = [&](int wofs, const float (&B)[9], float (&qo)[NACT], int n16, int g, const f4v *w4, const float *w8, const float *ab_lane) {
+    auto contract_with = [&](auto tg_c, auto load_a, const float (&B)[9], float (&qo)[NACT], int g, const float *ab_lane) {
+        constexpr int TG = decltype(tg_c)::value;             // row tiles per group (operands of a group are fetched together)
         float q[NACT + 1] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // the operands of group hh + 1 are fetched before the products of group hh are issued (two operand sets in registers)
+        f4v a0[2][TG], a1[2][TG];
+        float a8[2][TG];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            f4v acc[6];
+        for (int tt = 0; tt < TG; ++tt) load_a(tt, a0[0][tt], a1[0][tt], a8[0][tt]);
 #pragma unroll
-            for (int tt = 0; tt < 6; ++tt) {
-                const int t = 6 * hh + tt;
-                const f4v a0 = w4[wofs / 4 + (t * 2) * 64], a1 = w4[wofs / 4 + (t * 2 + 1) * 64];
-                const float a8 = w8[wofs + t * 64];
+        for (int hh = 0; hh < 12 / TG; ++hh) {
+            if (hh + 1 < 12 / TG) {
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt) load_a(TG * (hh + 1) + tt, a0[(hh + 1) & 1][tt], a1[(hh + 1) & 1][tt], a8[(hh + 1) & 1][tt]);
+            }
+            f4v acc[TG];
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) {
                 f4v c = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kb], B[kb], c, 0, 0, 0);
+                for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[hh & 1][tt][kb], B[kb], c, 0, 0, 0);
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb], B[4 + kb], c, 0, 0, 0);
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8, B[8], c, 0, 0, 0);
+                for (int kb = 0; kb < 4; ++kb) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[hh & 1][tt][kb], B[4 + kb], c, 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a8[hh & 1][tt], B[8], c, 0, 0, 0);
             }
 #pragma unroll
-            for (int tt = 0; tt < 6; ++tt) {
-                const int t = 6 * hh + tt;
+            for (int tt = 0; tt < TG; ++tt) {
+                const int t = TG * hh + tt;
                 const int Ct = (16 * t) % 36, At = (16 * t) / 36;
                 if (Ct + 12 < 36) {                          // the tile's 16 rows belong to one action
                     const f4v ab4 = *reinterpret_cast<const f4v *>(ab_lane + Ct);
@@ -323,26 +348,64 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         for (int a = 0; a < NACT; ++a) qo[a] = q[a];
         item_tree_sum<NACT>(qo);
     };
+    // ... A operands from the value function staged at float offset `wofs` of region W (two ds_read_b128 + one ds_read_b32 per tile)
+    auto contract = [&](int wofs, const float (&B)[9], float (&qo)[NACT], int n16, int g, const f4v *w4, const float *w8, const float *ab_lane) {
+        contract_with(std::integral_constant<int, SCG_E_TG>{}, [&](int t, f4v &a0, f4v &a1, float &a8) {
+            a0 = w4[wofs / 4 + (t * 2) * 64]; a1 = w4[wofs / 4 + (t * 2 + 1) * 64]; a8 = w8[wofs + t * 64];
+        }, B, qo, g, ab_lane);
+    };
+    // ... A operands straight from the caller's W_k[5][36][36] in memory: lane (n16, g) of tile t owns the nine consecutive floats
+    // W[16 t + n16][9 g .. 9 g + 8] (two 16-byte loads at 4-byte-aligned addresses and one float; rows >= 180: zeros). For the few
+    // envs that ENTER an option nobody in the block runs: its weights are not staged anywhere in this workgroup.
+    auto contract_g = [&](const float *Wk, const float (&B)[9], float (&qo)[NACT], int n16, int g, const float *ab_lane) {
+        struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+        contract_with(std::integral_constant<int, SCG_EO_TG>{}, [&](int t, f4v &a0, f4v &a1, float &a8) {
+            const int row = 16 * t + n16;
+            a0 = (f4v){0.0f, 0.0f, 0.0f, 0.0f}; a1 = a0; a8 = 0.0f;
+            if (row < NACT * 36) {
+                const float *pw = Wk + row * 36 + 9 * g;
+                const F4U u0 = *reinterpret_cast<const F4U *>(pw), u1 = *reinterpret_cast<const F4U *>(pw + 4);
+                a0 = (f4v){u0.x, u0.y, u0.z, u0.w}; a1 = (f4v){u1.x, u1.y, u1.z, u1.w}; a8 = pw[8];
+            }
+        }, B, qo, g, ab_lane);
+    };
     // W_k -> region W (+ dstf floats) in A-operand order (12 row tiles of the 180 x 36 matrix; entry (tile t, k-block kb,
     // lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 zero; per tile and lane the k-blocks 0..3 and 4..7 form two
     // float4 — one ds_read_b128 feeds four MFMAs — and k-block 8 sits apart), by `nth` threads with index `ht`: one thread
     // per DESTINATION float4, a 16-byte load at a 4-byte-aligned source address, one linear ds_write_b128.
     auto stage_w = [&](const float *Wk, int dstf, int ht, int nth) {
+        // (all of a thread's loads are issued before its first LDS store: one memory round trip per staging, not one per
+        //  loop iteration — the helper waves' W_0 took 10k cycles as three dependent load -> store rounds; nth >= 512)
         struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
         f4v *dst4 = reinterpret_cast<f4v *>(s_W + dstf);
-        for (int d = ht; d < 12 * 2 * 64; d += nth) {
-            const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
-            f4v v = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-            if (row < NACT * 36) {
-                const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
-                v = (f4v){w.x, w.y, w.z, w.w};
+        constexpr int N4 = 12 * 2 * 64, N1 = 12 * 64, MAXI = 3, MAXT = 2;
+        f4v v[MAXI];
+        float tl[MAXT];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int d = ht + i * nth;
+            v[i] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            if (d < N4) {
+                const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
+                if (row < NACT * 36) {
+                    const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
+                    v[i] = (f4v){w.x, w.y, w.z, w.w};
+                }
             }
-            dst4[d] = v;
         }
-        for (int z = ht; z < 12 * 64; z += nth) {                                 // k-block 8 of every tile
-            const int ln = z & 63, row = 16 * (z >> 6) + (ln & 15);
-            s_W[dstf + W_TAIL + z] = row < NACT * 36 ? Wk[row * 36 + 9 * (ln >> 4) + 8] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {                                          // k-block 8 of every tile
+            const int z = ht + i * nth;
+            tl[i] = 0.0f;
+            if (z < N1) {
+                const int ln = z & 63, row = 16 * (z >> 6) + (ln & 15);
+                if (row < NACT * 36) tl[i] = Wk[row * 36 + 9 * (ln >> 4) + 8];
+            }
         }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) { const int d = ht + i * nth; if (d < N4) dst4[d] = v[i]; }
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) { const int z = ht + i * nth; if (z < N1) s_W[dstf + W_TAIL + z] = tl[i]; }
     };
     // counters in LDS for hand-offs between SUBSETS of the workgroup's waves (s_barrier takes all sixteen): a producer
     // publishes with lds_arrive, a consumer polls with lds_await. Every awaited count is reached by waves that never
@@ -462,6 +525,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
             const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
             SCG_STAMP(2);                                         // P: physics, the pooled pair groups + hand-offs
+            int hkey = -1;
             if (valid) {
                 // bookkeeping (SPEC §1.4)
                 const int eps1 = ep0 + 1;
@@ -545,9 +609,27 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
                 }
                 if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
-                if (A.hist_next) atomicAdd(&A.hist_next[(e >> 8) * 8 + on], 1);   // next step's counting sort
+                hkey = (e >> 8) * 8 + on;                             // next step's counting sort: (row of 256 envs, option id)
             } else {
                 s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
+            }
+            if (A.hist_next) {
+                // one atomic per distinct (row, option id) of the wave instead of one per env: neighbours in the env order are
+                // neighbours in env id, so a wave holds about ten distinct keys — six times fewer atomics on 2048 hot counters, whose
+                // acknowledgements every later s_waitcnt vmcnt of this wave has to sit out
+#ifdef SCG_NO_HISTAGG
+                if (hkey >= 0) atomicAdd(&A.hist_next[hkey], 1);
+                uint64_t rem = 0;
+#else
+                uint64_t rem = __ballot(hkey >= 0);
+#endif
+                while (rem) {
+                    const int src = (int)__builtin_ctzll(rem);
+                    const int k0 = __shfl(hkey, src, 64);
+                    const uint64_t m = __ballot(hkey == k0);
+                    if (lane == src) atomicAdd(&A.hist_next[k0], (int)__popcll(m));
+                    rem &= ~m;
+                }
             }
         } else if (valid) {
             if (MODE == MODE_TRANS) {
@@ -584,8 +666,16 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     } else if (helpers && wave >= HELPER0) {
         const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index
         constexpr int NHT = N_HELP * 64;
+#ifdef SCG_STAMPS
+#define SCG_HSTAMP(SEC) do { if (ht == 0 && A.stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_stamp[(SEC)] += (unsigned)(t_ - hprev); hprev = t_; } } while (0)
+        unsigned long long hprev = stamp_prev;
+#else
+#define SCG_HSTAMP(SEC) do { } while (0)
+#endif
         stage_w(A.W, 0, ht, NHT);
+        SCG_HSTAMP(10);
         lds_await(&s_misc[M_C_PUBS], 64 * P_WAVES);                                    // the P waves have published s and the option ids
+        SCG_HSTAMP(11);
         decide_b();
         if (hw == 0 && lane == 0) { s_misc[M_KB] = kB; s_misc[M_MB] = mB; }
         if (kB >= 1) stage_w(A.W + (size_t)kB * NACT * NF, W_FLOATS, ht, NHT);
@@ -599,7 +689,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         // the root's update list (every env, one run per action, block order inside a run): each helper wave derives the
         // run geometry itself from ballots; helper wave 0 writes the list
+        SCG_HSTAMP(12);
         lds_await(&s_misc[M_C_PUB], 64 * P_WAVES);                                     // ... and the actions
+        SCG_HSTAMP(13);
         {
             uint64_t mk[P_WAVES][NACT];
             int at[P_WAVES];
@@ -634,6 +726,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
+        SCG_HSTAMP(14);
         run_u1(hw, N_HELP, 0);
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
@@ -644,13 +737,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         decide_b();
         if (lane == 0) { s_misc[M_KB] = kB; s_misc[M_MB] = mB; }
     }
-    if (helpers) { if (wave < LIST_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_LIST); else __builtin_amdgcn_s_setprio(0); }
+    if (helpers) { if ((unsigned)(wave - LIST0) < (unsigned)LIST_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_LIST); else __builtin_amdgcn_s_setprio(0); }
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s_next (and of s where no helper did it)
-    for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {
-        const int i = u & (BLOCK_ENVS - 1), d = (u / BLOCK_ENVS) & 3, sg = u / (4 * BLOCK_ENVS);
+    for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {     // thread -> (state sg, env i, variable d): four consecutive lanes write one env's 32 bytes
+        const int i = (u >> 2) & (BLOCK_ENVS - 1), d = u & 3, sg = u / (4 * BLOCK_ENVS);      // (one lane per env and variable 64 bytes apart was a 32-way bank conflict)
         if (i < nb && (MODE != MODE_QVAL || sg == 1) && !(helpers && sg == 0)) {
             const float sv = s_s[(4 * sg + d) * BLOCK_ENVS + i];
             s_z1[(i * 2 + sg) * 4 + d] = sincospi_cs(d < 2 ? sv : fmaf(sv, 0.25f, 0.5f));
@@ -671,12 +764,15 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     if (MODE == MODE_FUSED && tid < A.n_vf && A.cnts && tid != 0 && tid != kB && !((single >> tid) & 1u))
         A.cnts[(size_t)b * A.n_vf + tid] = 0;               // value functions without a pass here leave no slab
     const int n_pass0 = A.k_hi >= A.k_lo ? 1 : 0;
-    const int tid_k = tid, lane_k = lane;
     for (int pass = 0; pass < n_pass0 + MAX_VF; ++pass) {
         // Opaque copies of the thread and lane ids for the pass: every per-lane address of the pass body is loop-invariant, and
         // hoisted out of the pass loop they all stay live across it — the register allocator then spills them to scratch.
-        int tid_p = tid_k, lane_p = lane_k;
-        asm volatile("" : "+v"(tid_p), "+v"(lane_p));
+        // (Re-made from the hardware lane counter rather than copied from the kernel's tid: kept live across the loop the copy
+        //  itself was spilled, and the reload's s_waitcnt vmcnt — in order — made the env waves wait here for every global
+        //  store and atomic of phase P: 6-13k cycles in front of the pass.)
+        int lane_p;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+        const int tid_p = (wave << 6) | lane_p;
         const int tid = tid_p, lane = lane_p;
         int kA, kBp;                                        // value functions of this pass (kBp < 0: none)
         bool dense;                                         // E over position groups (pass 0) or over the compacted eval list
@@ -696,49 +792,67 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         SCG_STAMP(pass == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
         // ---- per-env flags of the pass (SPEC §5): ev bit v = the env needs Q_v(s_next, .) (bootstrap target and/or next
         // action); update items of A (all of them in pass 0 of a fused step: the root updates on every env) with their action
+        // The flags and lists are made by waves LIST0 .. LIST0 + 3 (thread ft <-> position ft), not by the env waves 0..3: those still
+        // have the global stores and atomics of phase P in flight, and any s_waitcnt vmcnt the compiler places in this stretch
+        // (a register reload is enough) would make them — and, at the next barrier, everybody — wait for all of that to drain.
+        const int ft = tid - LIST0 * 64, lw = wave - LIST0;
         bool evA = false, evB = false, up = false;
         int at = -1;
-        if (tid < nb) {
-            const int ot = s_ot[tid], on = s_on[tid];
+        if ((unsigned)ft < (unsigned)nb) {
+            const int ot = s_ot[ft], on = s_on[ft];
             const bool own = (MODE == MODE_FUSED && kA == 0) || ot == kA;
-            const bool gst = MODE == MODE_FUSED && !own && ((s_gs[tid] >> kA) & 1);       // SPEC §4.4 off-policy item
+            const bool gst = MODE == MODE_FUSED && !own && ((s_gs[ft] >> kA) & 1);       // SPEC §4.4 off-policy item
             up = (MODE != MODE_QVAL) && A.learn && (own || gst);
-            float rk = s_r0[tid], cont = s_c0[tid];
+            float rk = s_r0[ft], cont = s_c0[ft];
             if (MODE == MODE_FUSED && kA != 0) {
-                if (ot == kA) { rk = s_ro[tid]; cont = s_co[tid]; }
+                if (ot == kA) { rk = s_ro[ft]; cont = s_co[ft]; }
                 else {                                    // as if the env ran option kA: no time-out, no selection
-                    const unsigned ia = s_ia[tid], par2 = (A.parents >> (3 * kA)) & 7u;
+                    const unsigned ia = s_ia[ft], par2 = (A.parents >> (3 * kA)) & 7u;
                     const bool succ = (par2 == 0) ? (ia & 1u) : ((ia >> par2) & 1u);
                     const bool fail = !succ && !((ia >> kA) & 1u);
                     rk = rk + (succ ? A.r_succ : 0.0f);
                     cont = (cont == 0.0f || succ || fail) ? 0.0f : A.gamma;
                 }
-                s_rk[tid] = rk; s_ck[tid] = cont;
+                s_rk[ft] = rk; s_ck[ft] = cont;
             }
             evA = (on == kA) || (up && cont > 0.0f);
-            if (kBp >= 1) evB = (on == kBp) || (ot == kBp && A.learn && s_co[tid] > 0.0f);
-            at = s_a[tid];
-            s_ev[tid] = (uint8_t)((evA ? 1 : 0) | (evB ? 2 : 0));
+            if (kBp >= 1) evB = (on == kBp) || (ot == kBp && A.learn && s_co[ft] > 0.0f);
+            at = s_a[ft];
+            s_ev[ft] = (uint8_t)((evA ? 1 : 0) | (evB ? 2 : 0));
         }
         // compacted list: single passes -> the eval items of A; pass 0 -> the envs that need Q_B but lie outside B's prefix groups
         const int pg_b = (mB + 7) >> 3;                     // position groups that hold B's prefix
-        const bool cmp = dense ? (evB && (tid >> 3) >= pg_b) : evA;
+        const bool cmp = dense ? (evB && (ft >> 3) >= pg_b) : evA;
+#ifdef SCG_EO_UNITS
+        const bool eo_pass = pass == 0 && MODE == MODE_FUSED && eval_only != 0;
+        const int on_me = (unsigned)ft < (unsigned)nb ? (int)s_on[ft] : 0;
+        const bool eo = eo_pass && (unsigned)ft < (unsigned)nb && ((eval_only >> (on_me & 7)) & 1u);       // this env enters an evaluation-only value function
+        uint64_t me[MAX_VF];
+#endif
         uint64_t mb[1 + NACT];
-        if (wave < LIST_WAVES) {
+        if ((unsigned)lw < (unsigned)LIST_WAVES) {
             mb[0] = __ballot(cmp);
+#ifdef SCG_EO_UNITS
+#pragma unroll
+            for (int k = 1; k < MAX_VF; ++k) me[k] = eo_pass ? __ballot(eo && on_me == k) : 0ull;
+            if (lane >= 11 && lane < 10 + MAX_VF) {                                       // counts per value function: slots 11..15
+                const int k = lane - 10;
+                s_misc[M_CNT + lw * 16 + lane] = __popcll(k == 1 ? me[1] : k == 2 ? me[2] : k == 3 ? me[3] : k == 4 ? me[4] : me[5]);
+            }
+#endif
 #pragma unroll
             for (int a = 0; a < NACT; ++a) mb[1 + a] = __ballot(up && at == a);
-            const int lim = (kBp >= 1 ? mB : 0) - 64 * wave;                          // positions below mB belong to option kB
+            const int lim = (kBp >= 1 ? mB : 0) - 64 * lw;                          // positions below mB belong to option kB
             const uint64_t pre = lim >= 64 ? ~0ull : (lim > 0 ? ((1ull << lim) - 1ull) : 0ull);
             if (lane < 1 + 2 * NACT) {
                 const int sl = lane <= NACT ? lane : lane - NACT;
                 const uint64_t mine = sl == 0 ? mb[0] : sl == 1 ? mb[1] : sl == 2 ? mb[2] : sl == 3 ? mb[3] : sl == 4 ? mb[4] : mb[5];
-                s_misc[M_CNT + wave * 16 + lane] = __popcll(lane <= NACT ? mine : (mine & pre));
+                s_misc[M_CNT + lw * 16 + lane] = __popcll(lane <= NACT ? mine : (mine & pre));
             }
             if (dense) {                                    // per position group: which value functions need it
                 const uint64_t ma = __ballot(evA), mbb = __ballot(evB);
                 if (lane < 8) {
-                    const int pgrp = wave * 8 + lane;
+                    const int pgrp = lw * 8 + lane;
                     s_eflag[pgrp] = (uint8_t)((((ma >> (8 * lane)) & 0xffull) ? 1 : 0) | ((((mbb >> (8 * lane)) & 0xffull) && pgrp < pg_b) ? 2 : 0));
                 }
             }
@@ -772,18 +886,47 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
         }
         const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
-        if (wave < LIST_WAVES) {
+        // compacted eval lists in s_elist: [0, n_cmp) the pass's own compacted items, then (pass 0) one list per evaluation-only
+        // value function, every list starting at a multiple of 8 (a unit never mixes value functions)
+        int eo_cnt[MAX_VF], eo_base[MAX_VF], eo_units = 0;
+#pragma unroll
+        for (int k = 0; k < MAX_VF; ++k) { eo_cnt[k] = 0; eo_base[k] = 0; }
+#ifdef SCG_EO_UNITS
+        if (eo_pass) {
+            int base = (n_cmp + 7) & ~7;
+#pragma unroll
+            for (int k = 1; k < MAX_VF; ++k) {
+                int c = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < LIST_WAVES; ++w2) c += s_misc[M_CNT + w2 * 16 + 10 + k];
+                eo_cnt[k] = __builtin_amdgcn_readfirstlane(c);
+                eo_base[k] = base;
+                base += (eo_cnt[k] + 7) & ~7;
+                eo_units += (eo_cnt[k] + 7) >> 3;
+            }
+        }
+#endif
+        if ((unsigned)lw < (unsigned)LIST_WAVES) {
             const uint64_t below = (1ull << lane) - 1ull;
+#ifdef SCG_EO_UNITS
+            if (eo) {
+                int off = 0;
+                for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16 + 10 + on_me];
+                const uint64_t mine = on_me == 1 ? me[1] : on_me == 2 ? me[2] : on_me == 3 ? me[3] : on_me == 4 ? me[4] : me[5];
+                const int eb = on_me == 1 ? eo_base[1] : on_me == 2 ? eo_base[2] : on_me == 3 ? eo_base[3] : on_me == 4 ? eo_base[4] : eo_base[5];
+                s_elist[eb + off + __popcll(mine & below)] = (uint16_t)ft;
+            }
+#endif
             if (cmp) {
                 int off = 0;
-                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[M_CNT + w2 * 16];
-                s_elist[off + __popcll(mb[0] & below)] = (uint16_t)tid;
+                for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16];
+                s_elist[off + __popcll(mb[0] & below)] = (uint16_t)ft;
             }
             if (up && !u1_done) {
                 int off = 0;
                 const uint64_t mine = at == 0 ? mb[1] : at == 1 ? mb[2] : at == 2 ? mb[3] : at == 3 ? mb[4] : mb[5];
-                for (int w2 = 0; w2 < wave; ++w2) off += s_misc[M_CNT + w2 * 16 + 1 + at];
-                s_ulist[sel5(run_off, at) + off + __popcll(mine & below)] = (uint16_t)tid;
+                for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16 + 1 + at];
+                s_ulist[sel5(run_off, at) + off + __popcll(mine & below)] = (uint16_t)ft;
             }
         }
         block_lds_sync();
@@ -796,15 +939,59 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         // once and serve both value functions. Units [0, npg) are position groups (dense pass), the rest 8-item blocks of
         // the compacted list.
         const int npg = dense ? (nb + 7) >> 3 : 0;
-        const int n_units = npg + ((n_cmp + 7) >> 3);
+        const int n_own = (n_cmp + 7) >> 3;                 // units of the pass's own compacted list
+        const int n_units = npg + n_own + eo_units;
         if (n_units + nupd == 0) continue;
         {
         SCG_LANE_ROLES();
-        for (int u = wave; u < n_units; u += WAVES) {
-            const bool du = u < npg;
-            const int base = du ? 8 * u : 8 * (u - npg);
-            const int cnt = du ? min(8, nb - base) : min(8, n_cmp - base);
-            const unsigned fl = du ? (unsigned)__builtin_amdgcn_readfirstlane((int)s_eflag[u]) : (dense ? 2u : 1u);
+#ifdef SCG_STAMPS
+        const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // Dealing. Compacted units (the pass's own compacted list, then the evaluation-only value functions') go to the waves
+        // from the top down: unit c to wave 15 - c % 16. Position groups go to the waves from the bottom up, group j to wave
+        // j % 16 — except that a top wave holding a compacted unit (an evaluation-only unit waits on memory for its operands
+        // and costs about two LDS-fed evaluations) hands its SECOND position group (j = 16 + w, a single evaluation in the
+        // sorted order: the groups behind the option's prefix) to one of the waves below, which hold only three evaluations:
+        // measured per wave, the four top waves used to finish 15k cycles after everybody else.
+        const int n_cu = n_own + eo_units;
+#ifdef SCG_NO_REBAL
+        const int n_t = 0;
+#else
+        const int n_t = (dense && n_cu <= WAVES / 2 && npg > WAVES) ? n_cu : 0;   // top waves that give their second group away
+#endif
+        int my_du[3];
+        int my_dense = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) my_du[r] = -1;
+        if (n_t == 0) {                                      // plain round robin
+            my_dense = npg > wave ? (npg - wave + WAVES - 1) / WAVES : 0;
+        } else {
+            if (wave < npg) my_du[my_dense++] = wave;
+            if (wave < WAVES - n_t && wave + WAVES < npg) my_du[my_dense++] = wave + WAVES;
+            if (wave >= WAVES - 2 * n_t && wave < WAVES - n_t && wave + WAVES + n_t < npg) my_du[my_dense++] = wave + WAVES + n_t;
+        }
+        const int my_cu = n_cu > WAVES - 1 - wave ? (n_cu - (WAVES - 1 - wave) + WAVES - 1) / WAVES : 0;
+        // (compacted units first: the ones of evaluation-only value functions wait on memory for their operands, which the
+        //  other waves' LDS-fed units cover; a wave that ends on one leaves the matrix pipe idle)
+        for (int it = 0; it < my_dense + my_cu; ++it) {
+            const bool du = it >= my_cu;
+            const int di = it - my_cu;
+            const int u = du ? (n_t == 0 ? wave + WAVES * di : (di == 0 ? my_du[0] : di == 1 ? my_du[1] : my_du[2]))
+                             : (WAVES - 1 - wave) + WAVES * it;                                       // position group / compacted unit
+            int base, cnt, kg = -1;                          // kg >= 1: unit of evaluation-only value function kg (operands from memory)
+            unsigned fl;
+            if (du) { base = 8 * u; cnt = min(8, nb - base); fl = (unsigned)__builtin_amdgcn_readfirstlane((int)s_eflag[u]); }
+            else if (u < n_own) { base = 8 * u; cnt = min(8, n_cmp - base); fl = dense ? 2u : 1u; }
+            else {
+                int c = u - n_own;
+                base = 0; cnt = 0; fl = 1u;
+#pragma unroll
+                for (int k = 1; k < MAX_VF; ++k) {
+                    const int uk = (eo_cnt[k] + 7) >> 3;
+                    if (kg < 0 && c < uk) { kg = k; base = eo_base[k] + 8 * c; cnt = min(8, eo_cnt[k] - 8 * c); }
+                    if (kg < 0) c -= uk;
+                }
+            }
             if (!fl) continue;
             {
                 const int j = min(bi, cnt - 1);
@@ -816,6 +1003,19 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
             const bool have = ocol_item < cnt;
             const int il = du ? base + min(ocol_item, cnt - 1) : (int)s_elist[base + min(ocol_item, cnt - 1)];
+            if (kg >= 1) {                                   // an evaluation-only value function: only the next action's values are needed
+                float qo[NACT];
+                int n16o = n16, go = g;                      // (opaque copies: the twelve per-lane row addresses are loop-invariant and
+                asm volatile("" : "+v"(n16o), "+v"(go));     //  would otherwise be hoisted out of the unit loop and spilled)
+                contract_g(A.W + (size_t)kg * NACT * NF, B, qo, n16o, go, ab_lane);
+                if (out_lane && have) {
+                    float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                    orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                    orec[3].x = qo[4];
+                }
+                wave_lds_sync();
+                continue;
+            }
 #pragma unroll 1
             for (int v = 0; v < 2; ++v) {
                 if (!((fl >> v) & 1u)) continue;
@@ -841,8 +1041,148 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
             wave_lds_sync();
         }
+#ifdef SCG_STAMPS
+        if (pass == 0 && MODE == MODE_FUSED && A.stamps && lane == 0) s_stamp[32 + wave] += (unsigned)(__builtin_amdgcn_s_memtime() - e_t0);
+#endif
         }
         SCG_STAMP(pass == 0 ? 3 : 10);   // E (wave 0's share)
+#ifdef SCG_EO_VALU
+        // ---- evaluation-only value functions, on the vector pipe, behind this wave's E units (pass 0): Q_k(s_next, .) of the
+        // envs ENTERING an option nobody in this block runs (about 14 (value function, env) pairs per block on the bench workload).
+        // The pairs are enumerated in a fixed order by every wave and dealt from the top wave down (the low waves hold one E
+        // unit more); a wave evaluates its pair alone — the same fmaf chains as the MFMA (SPEC §3.1), so bit-identical to what a
+        // pass would have produced — with its private table area as scratch: no staging of W_k for the workgroup, no lists, no
+        // workgroup barrier. One lane owns one row of W_k (its 36-term chain is sequential); the rows come in through LDS:
+        // 16 rows = 2304 contiguous bytes per piece, read as coalesced 16-byte loads and handed to their lanes by conflict-free
+        // ds_read_b128 (row stride 36 dwords). Read per lane straight from memory (rounds 2-3: one 144-byte row per lane, 64
+        // different cache lines per load instruction) the 14 pairs of a CU kept its one texture path busy for ~19k cycles.
+        if (pass == 0 && MODE == MODE_FUSED && eval_only) {
+            SCG_STAMP(26);
+            float *tb = s_R + R_TAB + wave * E_TAB_FLOATS;
+            float2 *t_ab = reinterpret_cast<float2 *>(tb), *t_cd = t_ab + 36, *t_T = t_cd + 36;      // 36 + 36 + 180 float2
+            f4v *stage = reinterpret_cast<f4v *>(tb + 2 * (36 + 36 + 180));                         // 16 rows x 9 float4
+            static_assert(2 * (36 + 36 + 180) + 16 * 36 <= E_TAB_FLOATS && (2 * (36 + 36 + 180)) % 4 == 0, "pair scratch fits the wave's table area");
+            int pair = 0;
+            for (int k = 1; k < A.n_vf; ++k) {
+                if (!((eval_only >> k) & 1u)) continue;
+                const f4v *Wk4 = reinterpret_cast<const f4v *>(A.W + (size_t)k * NACT * NF);
+                for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
+                    const int ii = 64 * h + lane;
+                    uint64_t m = __ballot(ii < nb && s_on[ii] == k);
+                    while (m) {
+                        const int il = 64 * h + (int)__builtin_ctzll(m);
+                        m &= m - 1;
+#ifdef SCG_STAMPS
+                        if (tid == 0 && A.stamps) s_stamp[30] += 1;                         // (diagnostic) pairs in this block
+#endif
+                        if ((WAVES - 1 - (pair++ & (WAVES - 1))) != wave) continue;      // dealt from the top: the low waves hold more E units
+#ifdef SCG_STAMPS
+                        if (tid == 0 && A.stamps) s_stamp[29] += 1;                         // (diagnostic) ... of which wave 0 took
+#endif
+                        // tables of s_next: lane c < 36 owns AB[c] and CD[c] (c = 6 hi + lo)
+                        if (lane < 36) {
+                            const float4 *zp = reinterpret_cast<const float4 *>(s_z1 + (il * 2 + 1) * 4);
+                            const float4 za = zp[0], zc = zp[1];
+                            const int hi = (lane * 43) >> 8, lo = lane - 6 * hi;                  // lane / 6, lane % 6 for lane < 36
+                            float2 ab = zpow_sel(make_float2(za.z, za.w), lo), cd = zpow_sel(make_float2(zc.z, zc.w), lo);
+#pragma unroll
+                            for (int c = 1; c < 6; ++c) {                                         // row hi: hi chained products
+                                const float2 abn = cmul(ab, make_float2(za.x, za.y)), cdn = cmul(cd, make_float2(zc.x, zc.y));
+                                if (c <= hi) { ab = abn; cd = cdn; }
+                            }
+                            t_ab[lane] = make_float2(ab.x, -ab.y);
+                            t_cd[lane] = cd;
+                        }
+                        // T[row][re | im], row = 36 a + c12: the fmaf chain over c34 = 9 g + kb (kb outer, g inner)
+#pragma unroll 1
+                        for (int r0 = 0; r0 < 192; r0 += 64) {
+                            float wv[36];
+#pragma unroll
+                            for (int q = 0; q < 36; ++q) wv[q] = 0.0f;
+#ifdef SCG_EO_VALU_COALESCED
+                            {   // the round's 64 rows = 9216 contiguous bytes: nine coalesced 1-KB loads, all in flight together ...
+                                const int nf4r = 9 * max(0, min(64, NACT * 36 - r0));             // float4s of the round (<= 576)
+                                f4v ld[9];
+#pragma unroll
+                                for (int j = 0; j < 9; ++j) {
+                                    const int f4i = lane + 64 * j;
+                                    ld[j] = f4i < nf4r ? Wk4[r0 * 9 + f4i] : (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+                                }
+                                // ... then handed to their lanes 16 rows (144 float4s = 2304 bytes of scratch) at a time
+#pragma unroll
+                                for (int pc = 0; pc < 4; ++pc) {
+                                    wave_lds_sync();                                              // (the previous piece is read out)
+#pragma unroll
+                                    for (int j = 0; j < 9; ++j) {
+                                        if (64 * j + 63 >= 144 * pc && 64 * j < 144 * (pc + 1)) {     // (static) load j overlaps piece pc
+                                            const int f4p = 64 * j + lane - 144 * pc;
+                                            if (f4p >= 0 && f4p < 144) stage[f4p] = ld[j];
+                                        }
+                                    }
+                                    wave_lds_sync();
+                                    if ((lane >> 4) == pc) {
+#pragma unroll
+                                        for (int q4 = 0; q4 < 9; ++q4) {
+                                            const f4v w = stage[(lane & 15) * 9 + q4];
+                                            wv[4 * q4] = w[0]; wv[4 * q4 + 1] = w[1]; wv[4 * q4 + 2] = w[2]; wv[4 * q4 + 3] = w[3];
+                                        }
+                                    }
+                                }
+                            }
+#else
+                            if (r0 + lane < NACT * 36) {                                      // one 144-byte row per lane, straight from memory
+                                const f4v *wr = Wk4 + (r0 + lane) * 9;
+#pragma unroll
+                                for (int q4 = 0; q4 < 9; ++q4) {
+                                    const f4v w = wr[q4];
+                                    wv[4 * q4] = w[0]; wv[4 * q4 + 1] = w[1]; wv[4 * q4 + 2] = w[2]; wv[4 * q4 + 3] = w[3];
+                                }
+                            }
+#endif
+                            const int row = r0 + lane;
+                            float tre = 0.0f, tim = 0.0f;
+#pragma unroll
+                            for (int kb = 0; kb < 9; ++kb) {
+#pragma unroll
+                                for (int gg = 0; gg < 4; ++gg) {
+                                    const float2 cdv = t_cd[9 * gg + kb];
+                                    tre = fmaf(wv[9 * gg + kb], cdv.x, tre);
+                                    tim = fmaf(wv[9 * gg + kb], cdv.y, tim);
+                                }
+                            }
+                            if (row < NACT * 36) t_T[row] = make_float2(tre, tim);
+                        }
+                        wave_lds_sync();
+                        // q[a][g][part]: lane = 8 a + 2 g + part chains over its nine c12 in increasing order, then the tree
+                        float qv = 0.0f;
+                        {
+                            const int a = min(lane >> 3, NACT - 1), gq = (lane >> 1) & 3, part = lane & 1;
+                            // rows 36 a + c12 of group gq: c12 = 4 i + v with ((36 a) / 4 + i) % 4 == gq  ->  i = (gq - 9 a) & 3, + 4, + 8
+                            const int i0 = (gq - 9 * a) & 3;
+#pragma unroll
+                            for (int ii3 = 0; ii3 < 3; ++ii3) {
+                                const int i = i0 + 4 * ii3;                                  // i = 0..8: quad of rows 4 i .. 4 i + 3
+                                if (i < 9) {
+#pragma unroll
+                                    for (int v = 0; v < 4; ++v) {
+                                        const float2 tv = t_T[36 * a + 4 * i + v], av = t_ab[4 * i + v];
+                                        qv = fmaf(part ? tv.y : tv.x, part ? av.y : av.x, qv);
+                                    }
+                                }
+                            }
+                        }
+                        qv = qv + __shfl_xor(qv, 1, 64);                      // u_g = q_re + q_im
+                        qv = qv + __shfl_xor(qv, 2, 64);                      // u_0 + u_1 | u_2 + u_3
+                        qv = qv + __shfl_xor(qv, 4, 64);                      // (u_0 + u_1) + (u_2 + u_3)
+                        if (lane < 8 * NACT && (lane & 7) == 0)               // into the env's result line (orec[2].xyzw, orec[3].x)
+                            reinterpret_cast<float *>(A.outrec + (size_t)(e0 + il) * 4)[8 + (lane >> 3)] = qv;
+                        wave_lds_sync();
+                    }
+                }
+            }
+            SCG_STAMP(27);
+        }
+#endif
         // ---- U1 (pass 0 of a learning step: ran under phase P on the helper waves)
         if (MODE != MODE_QVAL && nupd > 0 && !u1_done) run_u1(wave, WAVES, n_units);   // dealt on behind E's blocks
         if (MODE == MODE_QVAL || nupd == 0) continue;
@@ -1014,14 +1354,15 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // bit-identical to a pass by construction, one barrier pair per round of EO_SLOTS value functions. (Rounds 2-3 evaluated
     // every pair on the vector pipe with W_k rows read per lane from global memory: with one workgroup per CU those strided
     // 16-byte gathers — 27 KB per pair through the CU's one texture path — were 19k cycles of nobody's time but this wave's.)
+#ifdef SCG_EO_MFMA
     if (MODE == MODE_FUSED && eval_only) {
         constexpr int EO_SLOTS = 4;
         static_assert(EO_SLOTS * (W_FLOATS + E_TAB_FLOATS) <= R_FLOATS && EO_SLOTS * 4 <= WAVES, "slots fit region R");
         unsigned todo = eval_only;
         while (todo) {
-            int tid_e = tid_k, lane_e = lane_k;             // (opaque per round, as in the pass loop: no hoisting, no spills)
-            asm volatile("" : "+v"(tid_e), "+v"(lane_e));
-            const int tid = tid_e, lane = lane_e;
+            int lane_e;                                     // (opaque per round, as in the pass loop: no hoisting, no spills)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            const int tid = (wave << 6) | lane_e, lane = lane_e;
             int ks[EO_SLOTS];
             int ns = 0;
 #pragma unroll
@@ -1034,7 +1375,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
             for (int sl = 0; sl < EO_SLOTS; ++sl)
                 if (sl < ns) stage_w(A.W + (size_t)ks[sl] * NACT * NF, sl * W_FLOATS, tid, THREADS);
+            SCG_STAMP(8);
             block_lds_sync();
+            SCG_STAMP(31);
             if ((wave & 3) == 0 && (wave >> 2) < ns) {
                 const int sl = wave >> 2;
                 const int k = sl == 0 ? ks[0] : sl == 1 ? ks[1] : sl == 2 ? ks[2] : ks[3];
@@ -1085,6 +1428,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             SCG_STAMP(27);
         }
     }
+#endif
     if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)
         block_lds_sync();
         if (tid == 0 && s_misc[M_FAIL])
@@ -1093,7 +1437,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #ifdef SCG_STAMPS
     if (MODE == MODE_FUSED && A.stamps) {
         __syncthreads();
-        if (tid < 32) A.stamps[(size_t)blockIdx.x * 32 + tid] += s_stamp[tid];
+        if (tid < STAMP_SLOTS) A.stamps[(size_t)blockIdx.x * STAMP_SLOTS + tid] += s_stamp[tid];
     }
 #endif
 }

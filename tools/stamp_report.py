@@ -23,18 +23,19 @@ nblk = n // lib.scg_block_envs()
 lib.scg_diag_stamps(ctx, None, 1)
 for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
-out = np.zeros((nblk, 32), np.uint64)
+out = np.zeros((nblk, 48), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
 names = ["phase P (rest: trace, hist, barrier)", "pass 0: phase Z + flags + (W staging)", "P: physics, pooled (env, edge) pair groups + hand-offs", "pass 0: E (eval, both VFs)", "pass 0: U1 (only when no helper ran it)",
-         "pass 0: Z + lists until the pass stamp", "pass 0: U2 (last chunk: wait)", "pass 0: wait before U2", "single passes: lists + W staging", "U2: own products of a chunk",
-         "single passes: E", "single passes: U1", "single passes: barrier at pass start", "single passes: U2 (last chunk)", "single passes: wait before U2", "slab stores",
+         "pass 0: Z + lists until the pass stamp", "pass 0: U2 (last chunk: wait)", "pass 0: wait before U2", "eval-only: staging (own share)", "U2: own products of a chunk",
+         "(helper: W_0 staged)", "(helper: + wait for the published states)", "(helper: + option, W_B, Z(s))", "(helper: + wait for the actions)", "(helper: + lists, hand-off)", "slab stores",
          "P: qcache gathers, Philox, action", "P: perm + state gathers", "P: physics, own part (refine, free flight, pair lists)", "P: bookkeeping, options, result line",
-         "U2: prologue / wait for the previous chunk's products", "U2: build", "U2: wait for the other waves' build", "flags + ballots", "W staging (when not under P)", "barrier behind the staging", "eval-only: wait for region R", "eval-only: staging + units on the matrix pipe", "(helper wave 8: kernel start -> its U1 done; not part of the total)", "(count: eval-only pairs wave 0 took)", "(count: eval-only pairs in the block)", "-"]
+         "U2: prologue / wait for the previous chunk's products", "U2: build", "U2: wait for the other waves' build", "flags + ballots", "W staging (when not under P)", "barrier behind the staging", "eval-only: wait for region R", "eval-only: staging + units on the matrix pipe", "(helper wave 8: kernel start -> its U1 done; not part of the total)", "(count: eval-only pairs wave 0 took)", "(count: eval-only pairs in the block)", "eval-only: barrier behind the staging"]
 mean = out.astype(np.float64).mean(0) / args.steps
-tot = mean.sum() - mean[28] - mean[29] - mean[30]
+tot = mean[:32].sum() - mean[28] - mean[29] - mean[30] - mean[10:15].sum()
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
 for nme, v in zip(names, mean): print(f"  {nme:36s} {v:10.0f}  {100*v/tot:5.1f} %")
-per_block = out.astype(np.float64).sum(1) / args.steps
+print("E phase per wave (cycles, mean over blocks):", np.round(mean[32:48]).astype(int).tolist())
+per_block = out[:, :32].astype(np.float64).sum(1) / args.steps
 print(f"per-block wave-0 total ticks per launch: min {per_block.min():.0f}  mean {per_block.mean():.0f}  max {per_block.max():.0f}"
       f"  (mean/max = {per_block.mean()/per_block.max():.2f}: one workgroup per CU, the launch lasts as long as its slowest)")
 print("  by block index (env order, 16 bins):", np.round(per_block.reshape(16, -1).mean(1)).astype(int).tolist())
