@@ -82,6 +82,8 @@ constexpr int M_UPD = 73;         // bit k: ... an UPDATE item
 constexpr int M_FAIL = 74;        // a bounded hand-off poll ran out (reported through the async status word)
 constexpr int M_C_PUBS = 77;      //   envs whose entry state and option id are published (the actions follow: M_C_PUB)
 constexpr int M_KB = 75, M_MB = 76; // the block's option (value function B of the merged pass) and its prefix length, published by wave HELPER0
+constexpr int M_ECTR = 79;         // next E unit to take (dynamic dealing)
+constexpr int M_EO = 80;           // [12] evaluation-only lists: [k] items of value function k (k = 1..5), [6 + k] their start in s_elist, [6] units in all
 constexpr int M_INTS = 128;
 static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
 
@@ -93,6 +95,9 @@ enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
 //   SCG_EO_VALU   on the vector pipe behind each wave's E units (rounds 2-3), [SCG_EO_VALU_COALESCED: rows through LDS]
 #if !defined(SCG_EO_MFMA) && !defined(SCG_EO_VALU)
 #define SCG_EO_UNITS 1
+#endif
+#if !defined(SCG_E_STATIC)
+#define SCG_E_DYN 1           // E units taken from an LDS counter (737.2 vs 731.5 M env-steps/s against the static deal)
 #endif
 #ifndef SCG_E_TG
 #define SCG_E_TG 4            // row tiles per operand group of the LDS-fed contraction (12 % SCG_E_TG == 0)
@@ -829,6 +834,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         const bool eo = eo_pass && (unsigned)ft < (unsigned)nb && ((eval_only >> (on_me & 7)) & 1u);       // this env enters an evaluation-only value function
         uint64_t me[MAX_VF];
 #endif
+        if (ft == 0) s_misc[M_ECTR] = 0;
         uint64_t mb[1 + NACT];
         if ((unsigned)lw < (unsigned)LIST_WAVES) {
             mb[0] = __ballot(cmp);
@@ -888,11 +894,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         const int nupd = run_off[NACT - 1] + run_len[NACT - 1];
         // compacted eval lists in s_elist: [0, n_cmp) the pass's own compacted items, then (pass 0) one list per evaluation-only
         // value function, every list starting at a multiple of 8 (a unit never mixes value functions)
-        int eo_cnt[MAX_VF], eo_base[MAX_VF], eo_units = 0;
+        // (their geometry is worked out by the list waves and published through s_misc: ten more wave-uniform values held
+        //  by all sixteen waves across the pass were ten more scalar registers spilled)
+        int eo_cnt[MAX_VF], eo_base[MAX_VF], eo_units_l = 0;
 #pragma unroll
         for (int k = 0; k < MAX_VF; ++k) { eo_cnt[k] = 0; eo_base[k] = 0; }
 #ifdef SCG_EO_UNITS
-        if (eo_pass) {
+        if (eo_pass && (unsigned)lw < (unsigned)LIST_WAVES) {
             int base = (n_cmp + 7) & ~7;
 #pragma unroll
             for (int k = 1; k < MAX_VF; ++k) {
@@ -902,7 +910,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 eo_cnt[k] = __builtin_amdgcn_readfirstlane(c);
                 eo_base[k] = base;
                 base += (eo_cnt[k] + 7) & ~7;
-                eo_units += (eo_cnt[k] + 7) >> 3;
+                eo_units_l += (eo_cnt[k] + 7) >> 3;
+            }
+            if (lw == 0 && lane < MAX_VF) {
+                const int k = lane;
+                s_misc[M_EO + k] = k == 0 ? 0 : k == 1 ? eo_cnt[1] : k == 2 ? eo_cnt[2] : k == 3 ? eo_cnt[3] : k == 4 ? eo_cnt[4] : eo_cnt[5];
+                s_misc[M_EO + 6 + k] = k == 0 ? eo_units_l : k == 1 ? eo_base[1] : k == 2 ? eo_base[2] : k == 3 ? eo_base[3] : k == 4 ? eo_base[4] : eo_base[5];
             }
         }
 #endif
@@ -940,10 +953,14 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         // the compacted list.
         const int npg = dense ? (nb + 7) >> 3 : 0;
         const int n_own = (n_cmp + 7) >> 3;                 // units of the pass's own compacted list
+#ifdef SCG_EO_UNITS
+        const int eo_units = eo_pass ? __builtin_amdgcn_readfirstlane(s_misc[M_EO + 6]) : 0;
+#else
+        const int eo_units = 0;
+#endif
         const int n_units = npg + n_own + eo_units;
         if (n_units + nupd == 0) continue;
         {
-        SCG_LANE_ROLES();
 #ifdef SCG_STAMPS
         const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -954,11 +971,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         // sorted order: the groups behind the option's prefix) to one of the waves below, which hold only three evaluations:
         // measured per wave, the four top waves used to finish 15k cycles after everybody else.
         const int n_cu = n_own + eo_units;
-#ifdef SCG_NO_REBAL
-        const int n_t = 0;
-#else
+#ifdef SCG_REBAL
         const int n_t = (dense && n_cu <= WAVES / 2 && npg > WAVES) ? n_cu : 0;   // top waves that give their second group away
-#endif
+#else
+        const int n_t = 0;                                   // (measured: 735 vs 744 M env-steps/s with the hand-over — the top waves are slow
+#endif                                                       //  whatever they hold: they are the youngest of their SIMDs)
         int my_du[3];
         int my_dense = 0;
 #pragma unroll
@@ -973,11 +990,25 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         const int my_cu = n_cu > WAVES - 1 - wave ? (n_cu - (WAVES - 1 - wave) + WAVES - 1) / WAVES : 0;
         // (compacted units first: the ones of evaluation-only value functions wait on memory for their operands, which the
         //  other waves' LDS-fed units cover; a wave that ends on one leaves the matrix pipe idle)
+#ifdef SCG_E_DYN
+        // units are taken from a counter in LDS by whichever wave is free: the compacted units first (the evaluation-only ones
+        // wait on memory for their operands), then the position groups in order — the option's prefix (two evaluations each)
+        // before the groups behind it (one): the big items first, the small ones fill the end
+        (void)my_dense; (void)my_cu; (void)my_du;
+        for (;;) {
+            int it = 0;
+            if (lane == 0) it = atomicAdd(&s_misc[M_ECTR], 1);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= n_cu + npg) break;
+            const bool du = it >= n_cu;
+            const int u = du ? it - n_cu : it;
+#else
         for (int it = 0; it < my_dense + my_cu; ++it) {
             const bool du = it >= my_cu;
             const int di = it - my_cu;
             const int u = du ? (n_t == 0 ? wave + WAVES * di : (di == 0 ? my_du[0] : di == 1 ? my_du[1] : my_du[2]))
                              : (WAVES - 1 - wave) + WAVES * it;                                       // position group / compacted unit
+#endif
             int base, cnt, kg = -1;                          // kg >= 1: unit of evaluation-only value function kg (operands from memory)
             unsigned fl;
             if (du) { base = 8 * u; cnt = min(8, nb - base); fl = (unsigned)__builtin_amdgcn_readfirstlane((int)s_eflag[u]); }
@@ -987,12 +1018,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 base = 0; cnt = 0; fl = 1u;
 #pragma unroll
                 for (int k = 1; k < MAX_VF; ++k) {
-                    const int uk = (eo_cnt[k] + 7) >> 3;
-                    if (kg < 0 && c < uk) { kg = k; base = eo_base[k] + 8 * c; cnt = min(8, eo_cnt[k] - 8 * c); }
+                    const int ck = __builtin_amdgcn_readfirstlane(s_misc[M_EO + k]), uk = (ck + 7) >> 3;
+                    if (kg < 0 && c < uk) { kg = k; base = __builtin_amdgcn_readfirstlane(s_misc[M_EO + 6 + k]) + 8 * c; cnt = min(8, ck - 8 * c); }
                     if (kg < 0) c -= uk;
                 }
             }
             if (!fl) continue;
+            SCG_LANE_ROLES();                               // (per unit: nothing of it lives across the loop)
             {
                 const int j = min(bi, cnt - 1);
                 build_tables(du ? base + j : (int)s_elist[base + j], 1, cp, bcol, cdk, abq);
@@ -1209,7 +1241,24 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         int Gtot = 0;
 #pragma unroll
         for (int a = 0; a < NACT; ++a) { Ga[a] = (run_len[a] + 3) >> 2; GBa[a] = (nBa[a] + 3) >> 2; Gtot += Ga[a]; }
-        const int nch = 4 * Gtot <= U2_CH ? 1 : 2;
+        // chunk geometry: UCH slots per chunk, nch chunks, chunk c holding groups [c Ga / nch, (c + 1) Ga / nch) of EVERY run
+#ifdef SCG_U2_DB
+        // (double-buffered build: 72-slot chunks in two buffers, built by the wave halves in turn, so that the build of chunk
+        //  c + 1 runs beside the products of chunk c; <= 67 groups need at most five chunks: sum_a ceil(Ga / 5) <= 17)
+        constexpr int UCH = 72, NBUILD = 8;
+        int nch = 1;
+        for (; nch < 5; ++nch) {
+            int need = 0;
+#pragma unroll
+            for (int a = 0; a < NACT; ++a) need += (Ga[a] + nch - 1) / nch;
+            if (4 * need <= UCH) break;
+        }
+#else
+        constexpr int UCH = U2_CH, NBUILD = WAVES;
+        const int nch = 4 * Gtot <= UCH ? 1 : 2;
+#endif
+        constexpr int USX = 2 * UCH + 4;                    // row stride of the chunk tables (floats): 292 / 148 = 36 / 20 mod 64, operand reads conflict-free
+        static_assert((3 * 36 * USX) * (UCH == U2_CH ? 1 : 2) <= R_FLOATS && NBUILD * 9 == UCH, "chunk tables fit region R");
         int wave_u = wave;
         asm volatile("" : "+s"(wave_u));                    // keeps the per-wave tile geometry inside the pass
         const bool haveB = nupdB > 0;
@@ -1222,106 +1271,131 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) accU[v][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
         }
-        float *ptabA = s_R, *ptabB = s_R + 36 * US, *ctab = s_R + 2 * 36 * US;
         const float *rA = (MODE == MODE_FUSED && kA != 0) ? s_rk : s_r0, *cA = (MODE == MODE_FUSED && kA != 0) ? s_ck : s_c0;
-        const int bi9 = lane_u % 9, cp9 = lane_u / 9;       // builder lanes of a chunk: (slot 9 wave + bi9, second index cp9 < 6)
-        for (int ch = 0; ch < nch; ++ch) {
-            // this chunk's share of every run: groups [gb[a], gb[a] + gc[a]) at slots [co[a], co[a + 1])
-            int gb[NACT], gc[NACT], co[NACT + 1];
+        const int bi9 = lane_u % 9, cp9 = lane_u / 9;       // builder lanes of a chunk: (slot 9 w + bi9, second index cp9 < 6)
+        // this chunk's share of every run: groups [gb[a], gb[a] + gc[a]) at slots [co[a], co[a + 1])
+        auto chunk_geo = [&](int ch, int (&gb)[NACT], int (&gc)[NACT], int (&co)[NACT + 1]) {
             co[0] = 0;
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
-                const int first = nch == 1 ? Ga[a] : (Ga[a] + 1) >> 1;
-                gb[a] = ch == 0 ? 0 : first;
-                gc[a] = ch == 0 ? first : Ga[a] - first;
+                const int lo = (ch * Ga[a]) / nch, hi = ((ch + 1) * Ga[a]) / nch;
+                gb[a] = lo; gc[a] = hi - lo;
                 co[a + 1] = co[a] + 4 * gc[a];
             }
-            if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
-            SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
-            {
-                const int slot = 9 * wave + bi9;
-                if (cp9 < 6 && slot < co[NACT]) {
-                    int a_ = 0;
+        };
+        auto u2_build = [&](int ch, float *tab, int bw /* this wave's index among the chunk's builders, < 0: none */) {
+            int gb[NACT], gc[NACT], co[NACT + 1];
+            chunk_geo(ch, gb, gc, co);
+            float *ptabA = tab, *ptabB = tab + 36 * USX, *ctab = tab + 2 * 36 * USX;
+            const int slot = 9 * bw + bi9;
+            if (bw >= 0 && cp9 < 6 && slot < co[NACT]) {
+                int a_ = 0;
 #pragma unroll
-                    for (int a = 1; a < NACT; ++a) a_ += slot >= co[a] ? 1 : 0;
-                    const int rl = sel5(run_len, a_), ro = sel5(run_off, a_), nbq = sel5(nBa, a_), l4b = 4 * sel5(GBa, a_);
-                    const int j = 4 * sel5(gb, a_) + slot - sel5(co, a_);     // slot of the padded run
-                    float *pdA = ptabA + cp9 * US + 2 * slot, *pdB = ptabB + cp9 * US + 2 * slot, *cdst = ctab + cp9 * US + 2 * slot;
-                    if (j < rl) {
-                        const int li = ro + j, il = s_ulist[li];
-                        const float rr = rA[il], cont = cA[il];
-                        const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
-                        const float d = target - s_qsa[li];
-                        float2 ab[6], cd[6];
-                        item_entries(s_z1 + (il * 2 + 0) * 4, cp9, ab, cd);
+                for (int a = 1; a < NACT; ++a) a_ += slot >= co[a] ? 1 : 0;
+                const int rl = sel5(run_len, a_), ro = sel5(run_off, a_), nbq = sel5(nBa, a_), l4b = 4 * sel5(GBa, a_);
+                const int j = 4 * sel5(gb, a_) + slot - sel5(co, a_);     // slot of the padded run
+                float *pdA = ptabA + cp9 * USX + 2 * slot, *pdB = ptabB + cp9 * USX + 2 * slot, *cdst = ctab + cp9 * USX + 2 * slot;
+                if (j < rl) {
+                    const int li = ro + j, il = s_ulist[li];
+                    const float rr = rA[il], cont = cA[il];
+                    const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
+                    const float d = target - s_qsa[li];
+                    float2 ab[6], cd[6];
+                    item_entries(s_z1 + (il * 2 + 0) * 4, cp9, ab, cd);
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            *reinterpret_cast<float2 *>(pdA + 6 * c * US) = make_float2(d * ab[c].x, d * (-ab[c].y));
-                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(cd[c].x, cd[c].y);
-                        }
-                        if (j < nbq) {                           // the item also updates value function B
-                            const float rb = s_ro[il], cb2 = s_co[il];
-                            const float tb = cb2 > 0.0f ? fmaf(cb2, s_maxq[BLOCK_ENVS + il], rb) : rb;
-                            const float db = tb - s_qsa[BLOCK_ENVS + li];
+                    for (int c = 0; c < 6; ++c) {
+                        *reinterpret_cast<float2 *>(pdA + 6 * c * USX) = make_float2(d * ab[c].x, d * (-ab[c].y));
+                        *reinterpret_cast<float2 *>(cdst + 6 * c * USX) = make_float2(cd[c].x, cd[c].y);
+                    }
+                    if (j < nbq) {                           // the item also updates value function B
+                        const float rb = s_ro[il], cb2 = s_co[il];
+                        const float tb = cb2 > 0.0f ? fmaf(cb2, s_maxq[BLOCK_ENVS + il], rb) : rb;
+                        const float db = tb - s_qsa[BLOCK_ENVS + li];
 #pragma unroll
-                            for (int c = 0; c < 6; ++c)
-                                *reinterpret_cast<float2 *>(pdB + 6 * c * US) = make_float2(db * ab[c].x, db * (-ab[c].y));
-                        } else if (j < l4b) {                    // null item of B's run (its C operand is masked in the MFMA loop)
+                        for (int c = 0; c < 6; ++c)
+                            *reinterpret_cast<float2 *>(pdB + 6 * c * USX) = make_float2(db * ab[c].x, db * (-ab[c].y));
+                    } else if (j < l4b) {                    // null item of B's run (its C operand is masked in the MFMA loop)
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) *reinterpret_cast<float2 *>(pdB + 6 * c * US) = make_float2(0.0f, 0.0f);
-                        }
-                    } else {                                     // null item padding a run to a multiple of 4
+                        for (int c = 0; c < 6; ++c) *reinterpret_cast<float2 *>(pdB + 6 * c * USX) = make_float2(0.0f, 0.0f);
+                    }
+                } else {                                     // null item padding a run to a multiple of 4
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            *reinterpret_cast<float2 *>(pdA + 6 * c * US) = make_float2(0.0f, 0.0f);
-                            *reinterpret_cast<float2 *>(cdst + 6 * c * US) = make_float2(0.0f, 0.0f);
-                        }
-                        if (j < l4b) {
+                    for (int c = 0; c < 6; ++c) {
+                        *reinterpret_cast<float2 *>(pdA + 6 * c * USX) = make_float2(0.0f, 0.0f);
+                        *reinterpret_cast<float2 *>(cdst + 6 * c * USX) = make_float2(0.0f, 0.0f);
+                    }
+                    if (j < l4b) {
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) *reinterpret_cast<float2 *>(pdB + 6 * c * US) = make_float2(0.0f, 0.0f);
-                        }
+                        for (int c = 0; c < 6; ++c) *reinterpret_cast<float2 *>(pdB + 6 * c * USX) = make_float2(0.0f, 0.0f);
                     }
                 }
             }
+        };
+        auto u2_mfma = [&](int ch, const float *tab) {
+            if (!worker) return;
+            int gb[NACT], gc[NACT], co[NACT + 1];
+            chunk_geo(ch, gb, gc, co);
+            const float *ptabA = tab, *ptabB = tab + 36 * USX, *ctab = tab + 2 * 36 * USX;
+            const int ngrp = sel5(gc, ja), g0 = sel5(gb, ja), so = sel5(co, ja);      // run ja's groups in this chunk, from group g0, at slot so
+            if (ngrp <= 0) return;
+            const int ngrpB = haveB ? min(max(j_GB - g0, 0), ngrp) : 0;          // ... of which B's
+            const int prow = min(16 * jm + n16, 35) * USX + 2 * g + 2 * so;
+            const float *paA = ptabA + prow, *paB = ptabB + prow;
+            const float *pb0 = ctab + n16 * USX + 2 * g + 2 * so, *pb1 = pb0 + 16 * USX,
+                        *pb2 = ctab + min(32 + n16, 35) * USX + 2 * g + 2 * so;
+            const int nvalid = j_nB - 4 * g0;                                    // B items of the run still real from group g0 on
+            for (int gi = 0; gi < ngrp; ++gi) {
+                const float2 a2 = *reinterpret_cast<const float2 *>(paA + 8 * gi);
+                float2 c0 = *reinterpret_cast<const float2 *>(pb0 + 8 * gi), c1 = *reinterpret_cast<const float2 *>(pb1 + 8 * gi),
+                       c2 = *reinterpret_cast<const float2 *>(pb2 + 8 * gi);
+                accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, a2.x, accU[0][0], 0, 0, 0);
+                accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, a2.x, accU[0][1], 0, 0, 0);
+                accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, a2.x, accU[0][2], 0, 0, 0);
+                accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, a2.y, accU[0][0], 0, 0, 0);
+                accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, a2.y, accU[0][1], 0, 0, 0);
+                accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, a2.y, accU[0][2], 0, 0, 0);
+                if (gi < ngrpB) {
+                    const float2 b2 = *reinterpret_cast<const float2 *>(paB + 8 * gi);
+                    if (4 * gi + 4 > nvalid && 4 * gi + g >= nvalid) {            // null item of B: both operands +0 (SPEC §5)
+                        c0 = make_float2(0.0f, 0.0f); c1 = c0; c2 = c0;
+                    }
+                    accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, b2.x, accU[1][0], 0, 0, 0);
+                    accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, b2.x, accU[1][1], 0, 0, 0);
+                    accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, b2.x, accU[1][2], 0, 0, 0);
+                    accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, b2.y, accU[1][0], 0, 0, 0);
+                    accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b2.y, accU[1][1], 0, 0, 0);
+                    accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, b2.y, accU[1][2], 0, 0, 0);
+                }
+            }
+        };
+#ifdef SCG_U2_DB
+        constexpr int BUF = 3 * 36 * USX;
+        u2_build(0, s_R, wave < NBUILD ? wave : -1);         // chunk c is built by waves 8 (c & 1) .. 8 (c & 1) + 7 into buffer c & 1
+        SCG_STAMP(21);
+        block_lds_sync();
+        SCG_STAMP(22);
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch + 1 < nch) {
+                const int hb = (ch + 1) & 1;
+                u2_build(ch + 1, s_R + hb * BUF, (wave >> 3) == hb ? (wave & 7) : -1);
+            }
+            SCG_STAMP(20);
+            u2_mfma(ch, s_R + (ch & 1) * BUF);
+            SCG_STAMP(9);
+            if (ch + 1 < nch) block_lds_sync();              // chunk ch + 1 is built, chunk ch's buffer is free again
+        }
+#else
+        for (int ch = 0; ch < nch; ++ch) {
+            if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
+            SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
+            u2_build(ch, s_R, wave);
             SCG_STAMP(21);                                       // (diagnostic) U2: build
             block_lds_sync();                                    // operands visible
             SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
-            if (worker) {
-                const int ngrp = sel5(gc, ja), g0 = sel5(gb, ja), so = sel5(co, ja);      // run ja's groups in this chunk, from group g0, at slot so
-                if (ngrp > 0) {
-                    const int ngrpB = haveB ? min(max(j_GB - g0, 0), ngrp) : 0;          // ... of which B's
-                    const int prow = min(16 * jm + n16, 35) * US + 2 * g + 2 * so;
-                    const float *paA = ptabA + prow, *paB = ptabB + prow;
-                    const float *pb0 = ctab + n16 * US + 2 * g + 2 * so, *pb1 = pb0 + 16 * US,
-                                *pb2 = ctab + min(32 + n16, 35) * US + 2 * g + 2 * so;
-                    const int nvalid = j_nB - 4 * g0;                                    // B items of the run still real from group g0 on
-                    for (int gi = 0; gi < ngrp; ++gi) {
-                        const float2 a2 = *reinterpret_cast<const float2 *>(paA + 8 * gi);
-                        float2 c0 = *reinterpret_cast<const float2 *>(pb0 + 8 * gi), c1 = *reinterpret_cast<const float2 *>(pb1 + 8 * gi),
-                               c2 = *reinterpret_cast<const float2 *>(pb2 + 8 * gi);
-                        accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, a2.x, accU[0][0], 0, 0, 0);
-                        accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, a2.x, accU[0][1], 0, 0, 0);
-                        accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, a2.x, accU[0][2], 0, 0, 0);
-                        accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, a2.y, accU[0][0], 0, 0, 0);
-                        accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, a2.y, accU[0][1], 0, 0, 0);
-                        accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, a2.y, accU[0][2], 0, 0, 0);
-                        if (gi < ngrpB) {
-                            const float2 b2 = *reinterpret_cast<const float2 *>(paB + 8 * gi);
-                            if (4 * gi + 4 > nvalid && 4 * gi + g >= nvalid) {            // null item of B: both operands +0 (SPEC §5)
-                                c0 = make_float2(0.0f, 0.0f); c1 = c0; c2 = c0;
-                            }
-                            accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, b2.x, accU[1][0], 0, 0, 0);
-                            accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, b2.x, accU[1][1], 0, 0, 0);
-                            accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, b2.x, accU[1][2], 0, 0, 0);
-                            accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, b2.y, accU[1][0], 0, 0, 0);
-                            accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b2.y, accU[1][1], 0, 0, 0);
-                            accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, b2.y, accU[1][2], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+            u2_mfma(ch, s_R);
             SCG_STAMP(9);                                        // (diagnostic) U2: this wave's own products of the chunk
         }
+#endif
         SCG_STAMP(pass == 0 ? 6 : 13);   // U2
         // the block partials straight from the accumulators (zeros for an empty run). The tiles were accumulated
         // TRANSPOSED (A operand = CDT rows, B operand = PT rows; fma(a, b, c) = fma(b, a, c)), so register v of lane (n16, g)

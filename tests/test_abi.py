@@ -84,6 +84,9 @@ def test_async_status_word_decoding(pkg):
     rc = lib.scg_decode_async_word(0x1 | (0x100 << 3), buf, 256)
     assert rc == -5 and b"scg_fit_initiation" in buf.value and b"0x8" in buf.value and b"unchanged" in buf.value
     assert lib.scg_decode_async_word(0x80000000, buf, 256) == -5 and b"unknown" in buf.value
+    rc = lib.scg_decode_async_word(0x2, buf, 256)                      # SCG_ASYNC_STEP_HANDOFF (round 4): a blown hand-off poll in scg_step
+    assert rc == -5 and b"scg_step" in buf.value and b"hand-off poll" in buf.value
+    assert lib.scg_decode_async_word(0x2 | 0x1, buf, 256) == -5 and b"scg_step" in buf.value    # the step's failure is named first
     assert lib.scg_decode_async_word(0x1, None, 0) == -5              # no buffer: status only
     small = C.create_string_buffer(8)
     assert lib.scg_decode_async_word(0x1, small, 8) == -5 and len(small.value) == 7      # truncated, terminated

@@ -98,3 +98,58 @@ def test_fit_with_no_patience_is_exact_or_reports_and_leaves_the_rows_alone():
         assert np.array_equal(got, w_o)
     ctx.clear_async_error()
     ctx.set_fit_timeout(2.0)
+
+
+def test_step_handoff_failure_is_reported_like_any_asynchronous_failure():
+    """A hand-off poll inside the step kernel that runs out ORs SCG_ASYNC_STEP_HANDOFF into the status word:
+    the next entry point refuses with SCG_ERR_ASYNC and names the step, and clearing re-arms the context."""
+    from skill_chaining_with_graphs_amd._lib import ASYNC_STEP_HANDOFF
+    from skill_chaining_with_graphs_amd.core import EnvState
+    ctx, orc, m = make_pair("pinball_simple", 300, n_options=1)
+    st = EnvState(300, ctx.device, m)
+    W = torch.zeros(2 * 5 * 1296, device="cuda:0"); clf = torch.zeros(2 * 8, device="cuda:0")
+    ctx.step(st, W, clf, 0, 0)
+    assert ctx.async_status(synchronize=True) == 0                        # a healthy step raises nothing
+    ctx.lib.scg_debug_raise_async(ctx._ctx, C.c_uint32(ASYNC_STEP_HANDOFF))  # what td_kernel writes when a bounded poll runs out
+    with pytest.raises(ScgError, match="hand-off poll"):
+        ctx.step(st, W, clf, 0, 1)
+    ctx.clear_async_error()
+    ctx.step(st, W, clf, 0, 1)
+    assert ctx.async_status(synchronize=True) == 0
+
+
+def test_announced_trigger_buffers_are_held_and_validated():
+    """ADVICE r3 (medium) / VERDICT r3 item 7: scg_arm_collect keeps raw device pointers that every later scg_step reads.
+    (i) the Python wrapper holds the announced tensors itself, so dropping the caller's references is harmless;
+    (ii) at the C-ABI, a step with an announced buffer that is no longer device memory is refused (SCG_ERR_STATE) instead
+    of launched, and the trigger is disarmed."""
+    import gc
+    from skill_chaining_with_graphs_amd.core import EnvState, _ptr
+    ctx, orc, m = make_pair("pinball_simple", 512, n_options=1)
+    st = EnvState(512, ctx.device, m)
+    W = torch.zeros(2 * 5 * 1296, device="cuda:0"); clf = torch.zeros(2 * 8, device="cuda:0")
+    ctx.set_trace_buffers(16)
+    xy = torch.zeros(2 * 1024, device="cuda:0"); lab = torch.zeros(1024, dtype=torch.uint8, device="cuda:0")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda:0"); prev = torch.zeros(512, dtype=torch.uint8, device="cuda:0")
+    ctx.step(st, W, clf, 0, 0)
+    ctx.collect_examples(1, prev, 4, 4, xy, lab, cnt)                      # rearm=True: the library now holds prev / cnt addresses
+    assert ctx._armed is not None and ctx._armed[0] is prev and ctx._armed[1] is cnt
+    del prev, cnt
+    gc.collect(); torch.cuda.empty_cache()
+    ctx.step(st, W, clf, 0, 1)                                             # reads the announced buffers: still alive inside ctx._armed
+    torch.cuda.synchronize()
+    prev2, cnt2 = torch.zeros(512, dtype=torch.uint8, device="cuda:0"), torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    ctx.collect_examples(1, prev2, 4, 4, xy, lab, cnt2)                    # new buffers: the old pair is released
+    assert ctx._armed[0] is prev2
+    ctx.disarm_collect()
+    assert ctx._armed is None
+    # (ii) straight at the C-ABI: announce a buffer, free it for real, step
+    big = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda:0")        # its own 64 MiB segment: goes back to the driver on empty_cache
+    cnt3 = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    ctx._call("scg_arm_collect", C.c_uint32(1), C.c_void_p(big.data_ptr()), 4, 4, _ptr(cnt3))
+    del big
+    gc.collect(); torch.cuda.empty_cache()
+    with pytest.raises(ScgError, match="no longer device memory"):
+        ctx.step(st, W, clf, 0, 2)
+    ctx.step(st, W, clf, 0, 2)                                             # disarmed by the refusal: steps run again
+    assert ctx.async_status(synchronize=True) == 0
