@@ -32,9 +32,12 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
 
 
 class ScgContext:
+    # r_option_success defaults to the task goal's 10 000: a completion reward that is small against the step costs an option
+    # pays on its way (-1 / -5 per step) makes LEAVING the initiation set at once (termination is worth 0) the option's best
+    # policy, and the chain then hurts (profiles/r04_chain_evidence_rsucc50.txt against _rsucc10000.txt)
     def __init__(self, n_envs: int, n_options: int, pmap: PinballMap, *, device: int = 0, seed: int = 0,
                  env_id_base: int = 0, gamma: float = 0.99, alpha: float = 1e-3, epsilon: float = 0.05,
-                 r_option_success: float = 100.0, max_episode_steps: int = 10000,
+                 r_option_success: float = 10000.0, max_episode_steps: int = 10000,
                  max_option_steps: int = 250):
         if not torch.cuda.is_available():
             raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")

@@ -82,6 +82,7 @@ constexpr int M_UPD = 73;         // bit k: ... an UPDATE item
 constexpr int M_FAIL = 74;        // a bounded hand-off poll ran out (reported through the async status word)
 constexpr int M_C_PUBS = 77;      //   envs whose entry state and option id are published (the actions follow: M_C_PUB)
 constexpr int M_KB = 75, M_MB = 76; // the block's option (value function B of the merged pass) and its prefix length, published by wave HELPER0
+constexpr int M_U1CTR = 78;        // next U1 column block to take (helper waves, dynamic dealing)
 constexpr int M_ECTR = 79;         // next E unit to take (dynamic dealing)
 constexpr int M_EO = 80;           // [12] evaluation-only lists: [k] items of value function k (k = 1..5), [6 + k] their start in s_elist, [6] units in all
 constexpr int M_INTS = 128;
@@ -223,14 +224,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // U1: Q(s, a_t) of the update items, per action run, 8 items per wave-iteration: the contraction of E on the 3 row
     // tiles that hold action a's rows, for value function A and — while the column block still holds B items — for B on
     // the SAME tables -> s_qsa[v][list position]. The column blocks of all runs are dealt to `nw` waves.
-    auto run_u1 = [&](int wv, int nw, int base) {
+    auto u1_block = [&](int a, int cb) {
         SCG_LANE_ROLES();
-#pragma unroll 1
-        for (int a = 0; a < NACT; ++a) {
+        {
             const int t0 = (36 * a) >> 4;                        // first of the 3 row tiles holding action a's rows
             const int cnt = sel5(run_len, a), cntB = sel5(nBa, a), ro = sel5(run_off, a);
             const uint16_t *lst = s_ulist + ro;
-            for (int cb = (((wv - base) % nw) + nw) % nw; 8 * cb < cnt; cb += nw) {
+            {
                 build_tables(lst[8 * cb + min(bi, cnt - 8 * cb - 1)], 0, cp, bcol, cdk, abq);
                 wave_lds_sync();
                 float B[9];
@@ -297,7 +297,32 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 else tiles(std::integral_constant<int, 1>{});
                 wave_lds_sync();
             }
+        }
+    };
+    // ... the column blocks of all runs dealt to `nw` waves in advance (single passes: behind E's units) ...
+    auto run_u1 = [&](int wv, int nw, int base) {
+#pragma unroll 1
+        for (int a = 0; a < NACT; ++a) {
+            const int cnt = sel5(run_len, a);
+            for (int cb = (((wv - base) % nw) + nw) % nw; 8 * cb < cnt; cb += nw) u1_block(a, cb);
             base += (cnt + 7) >> 3;
+        }
+    };
+    // ... or taken from a counter in LDS by whichever helper wave is free (under phase P the waves run at very different
+    // rates beside the env waves of their SIMDs, and a block with option items costs twice one without)
+    auto run_u1_dyn = [&]() {
+        int nbk[NACT], tot = 0;
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) { nbk[a] = (run_len[a] + 7) >> 3; tot += nbk[a]; }
+        for (;;) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&s_misc[M_U1CTR], 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= tot) break;
+            int a = 0;
+#pragma unroll
+            for (int aa = 0; aa < NACT - 1; ++aa) { if (a == aa && j >= nbk[aa]) { j -= nbk[aa]; a = aa + 1; } }
+            u1_block(a, j);
         }
     };
     // Q(sigma, .) of the 8 items whose tables sit in this wave's private area, for the value function staged at float offset
@@ -732,7 +757,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
         SCG_HSTAMP(14);
+#ifdef SCG_U1_STATIC
         run_u1(hw, N_HELP, 0);
+#else
+        run_u1_dyn();
+#endif
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
@@ -960,6 +989,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #endif
         const int n_units = npg + n_own + eo_units;
         if (n_units + nupd == 0) continue;
+#ifdef SCG_PRIO_E_YOUNG
+        if (helpers && pass == 0) { if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(SCG_PRIO_E_YOUNG); else __builtin_amdgcn_s_setprio(0); }   // (A/B knob: the younger half of every SIMD first)
+#endif
         {
 #ifdef SCG_STAMPS
         const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
@@ -1242,23 +1274,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
         for (int a = 0; a < NACT; ++a) { Ga[a] = (run_len[a] + 3) >> 2; GBa[a] = (nBa[a] + 3) >> 2; Gtot += Ga[a]; }
         // chunk geometry: UCH slots per chunk, nch chunks, chunk c holding groups [c Ga / nch, (c + 1) Ga / nch) of EVERY run
-#ifdef SCG_U2_DB
-        // (double-buffered build: 72-slot chunks in two buffers, built by the wave halves in turn, so that the build of chunk
-        //  c + 1 runs beside the products of chunk c; <= 67 groups need at most five chunks: sum_a ceil(Ga / 5) <= 17)
-        constexpr int UCH = 72, NBUILD = 8;
-        int nch = 1;
-        for (; nch < 5; ++nch) {
-            int need = 0;
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) need += (Ga[a] + nch - 1) / nch;
-            if (4 * need <= UCH) break;
-        }
-#else
+        // (a double-buffered build — 72-slot chunks in two buffers, built by the wave halves in turn beside the products of the
+        //  chunk before — measured 678 against 731 M env-steps/s: five chunks, six barriers, half-empty builder waves;
+        //  profiles/r04_u2_double_buffer.diff)
         constexpr int UCH = U2_CH, NBUILD = WAVES;
         const int nch = 4 * Gtot <= UCH ? 1 : 2;
-#endif
         constexpr int USX = 2 * UCH + 4;                    // row stride of the chunk tables (floats): 292 / 148 = 36 / 20 mod 64, operand reads conflict-free
-        static_assert((3 * 36 * USX) * (UCH == U2_CH ? 1 : 2) <= R_FLOATS && NBUILD * 9 == UCH, "chunk tables fit region R");
+        static_assert(3 * 36 * USX <= R_FLOATS && NBUILD * 9 == UCH, "chunk tables fit region R");
         int wave_u = wave;
         asm volatile("" : "+s"(wave_u));                    // keeps the per-wave tile geometry inside the pass
         const bool haveB = nupdB > 0;
@@ -1278,7 +1300,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             co[0] = 0;
 #pragma unroll
             for (int a = 0; a < NACT; ++a) {
-                const int lo = (ch * Ga[a]) / nch, hi = ((ch + 1) * Ga[a]) / nch;
+                const int half = Ga[a] >> 1;                            // chunk 0 of two: the first floor(Ga / 2) groups, chunk 1 the rest
+                const int lo = ch == 0 ? 0 : half, hi = (nch == 1 || ch == 1) ? Ga[a] : half;
                 gb[a] = lo; gc[a] = hi - lo;
                 co[a + 1] = co[a] + 4 * gc[a];
             }
@@ -1368,23 +1391,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
             }
         };
-#ifdef SCG_U2_DB
-        constexpr int BUF = 3 * 36 * USX;
-        u2_build(0, s_R, wave < NBUILD ? wave : -1);         // chunk c is built by waves 8 (c & 1) .. 8 (c & 1) + 7 into buffer c & 1
-        SCG_STAMP(21);
-        block_lds_sync();
-        SCG_STAMP(22);
-        for (int ch = 0; ch < nch; ++ch) {
-            if (ch + 1 < nch) {
-                const int hb = (ch + 1) & 1;
-                u2_build(ch + 1, s_R + hb * BUF, (wave >> 3) == hb ? (wave & 7) : -1);
-            }
-            SCG_STAMP(20);
-            u2_mfma(ch, s_R + (ch & 1) * BUF);
-            SCG_STAMP(9);
-            if (ch + 1 < nch) block_lds_sync();              // chunk ch + 1 is built, chunk ch's buffer is free again
-        }
-#else
         for (int ch = 0; ch < nch; ++ch) {
             if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
             SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
@@ -1395,7 +1401,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             u2_mfma(ch, s_R);
             SCG_STAMP(9);                                        // (diagnostic) U2: this wave's own products of the chunk
         }
-#endif
         SCG_STAMP(pass == 0 ? 6 : 13);   // U2
         // the block partials straight from the accumulators (zeros for an empty run). The tiles were accumulated
         // TRANSPOSED (A operand = CDT rows, B operand = PT rows; fma(a, b, c) = fma(b, a, c)), so register v of lane (n16, g)

@@ -21,7 +21,7 @@ ap.add_argument("--options", type=int, default=3); ap.add_argument("--alpha", ty
 ap.add_argument("--warm", type=int, default=3000); ap.add_argument("--after", type=int, default=3000)
 ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3])
 ap.add_argument("--gestation", type=int, default=200)
-ap.add_argument("--r-succ", type=float, default=50.0, help="option completion reward (SPEC 4.2 r_option_success)")
+ap.add_argument("--r-succ", type=float, default=10000.0, help="option completion reward (SPEC 4.2 r_option_success)")
 ap.add_argument("--max-option-steps", type=int, default=200)
 ap.add_argument("--json", default=None, help="also write the rows as JSON lines to this file")
 a = ap.parse_args()
