@@ -66,7 +66,7 @@ except (OSError, ValueError):
     pass
 
 
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")      # newest first
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")      # newest first
 
 
 def measured_traffic(envs_per_gpu, n_options):
@@ -169,17 +169,18 @@ def extra_measurements(steps, warmup):
     import torch
     from skill_chaining_with_graphs_amd import SkillChainingAgent
     ex = {}
-    # configs[1]
+    # configs[1], on the throughput build (256-env blocks: 16 workgroups on 256 CUs) and on the small-batch build (64-env blocks)
     n1 = 4096
-    ag = SkillChainingAgent(MAP, n1, 1, seed=0, **HP)
-    ag.clf.copy_(torch.as_tensor(chain_discs(ag.map, 1)))
-    ag.enable_option(1)
-    ag.init_weights(std=1e-3, seed=0)
-    ag.domain.reset_random(seed=1000, v_max=1.0)
-    dt = _time_steps(ag, max(steps, 200), warmup)
-    ex["config1_4096_envs_root_plus_1_option"] = {"value": n1 / dt, "unit": "env-steps/s", "us_per_step": dt * 1e6,
-                                                   "workgroups": -(-n1 // scg_block_envs()), "envs_in_an_option_at_end": int((ag.state.option_id > 0).sum())}
-    del ag
+    for blk, key in ((256, "config1_4096_envs_root_plus_1_option"), (64, "config1_4096_envs_root_plus_1_option_64_env_blocks")):
+        ag = SkillChainingAgent(MAP, n1, 1, seed=0, block_envs=blk, **HP)
+        ag.clf.copy_(torch.as_tensor(chain_discs(ag.map, 1)))
+        ag.enable_option(1)
+        ag.init_weights(std=1e-3, seed=0)
+        ag.domain.reset_random(seed=1000, v_max=1.0)
+        dt = _time_steps(ag, max(steps, 200), warmup)
+        ex[key] = {"value": n1 / dt, "unit": "env-steps/s", "us_per_step": dt * 1e6, "block_envs": ag.ctx.block_envs,
+                   "workgroups": -(-n1 // ag.ctx.block_envs), "envs_in_an_option_at_end": int((ag.state.option_id > 0).sum())}
+        del ag
     # configs[2] on discovered options
     hp = dict(HP, alpha=0.02, r_option_success=10000.0)       # a learning rate at which the root reaches the goal within the untimed
     ag = SkillChainingAgent(MAP, ENVS_PER_GPU, N_OPTIONS, seed=0, **hp)     # warm-up; completion reward of the goal's scale (DESIGN: chain evidence)
@@ -205,11 +206,6 @@ def extra_measurements(steps, warmup):
     return ex
 
 
-def scg_block_envs():
-    import skill_chaining_with_graphs_amd as scg
-    return int(scg.block_envs())
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +216,8 @@ def main():
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = CPU-side rehearsal of the N>1 path on a 1-GPU box (every rank computes on cuda:0)")
+    ap.add_argument("--block-envs", type=int, default=None, choices=[64, 128, 256],
+                    help="SPEC §5 block size = library build (default 256, the throughput build; 64 / 128: the small-batch builds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learn", action="store_true", help="diagnostic: act + physics + qcache only")
     ap.add_argument("--diag-no-td", action="store_true", help="diagnostic: physics + option logic only")
@@ -276,7 +274,8 @@ def main():
     n_opt = args.options
     lo = rank * n_local
     group = dist.group.WORLD if (distributed and args.shared_weights) else None
-    agent = SkillChainingAgent(MAP, n_local, n_opt, device=local_rank, seed=0, env_id_base=lo, group=group, **HP)
+    agent = SkillChainingAgent(MAP, n_local, n_opt, device=local_rank, seed=0, env_id_base=lo, group=group,
+                               block_envs=args.block_envs, **HP)
     agent.clf.copy_(torch.as_tensor(chain_discs(agent.map, n_opt)))
     for k in range(1, n_opt + 1):
         agent.enable_option(k)
@@ -351,6 +350,7 @@ def main():
                                    f"root + {n_opt} chained options (synthetic nested-disc initiation sets), "
                                    f"{'shared option-Q weights, RCCL all-reduce of dW' if group is not None else 'independent env shards, no collective'}",
                        "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP,
+                       "block_envs": agent.ctx.block_envs,
                        "untimed_ramp_steps": args.ramp,      # step-batches run BEFORE the warm-up: clocks up, env order prepared;
                                                               # `value` is therefore a steady-state figure
                        "backend": ("none" if not distributed else args.backend)},
@@ -363,7 +363,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                         "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 46 % busy), not HBM-bound (SURVEY.md \u00a78d, "
+                         "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 50 % busy), not HBM-bound (SURVEY.md \u00a78d, "
                                  "DESIGN.md): see `mfma` for the binding roofline"},
         }
         # the binding (matrix-pipe) roofline: algorithmic flops of the TD items this rank processed per step

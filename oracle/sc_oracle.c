@@ -598,6 +598,8 @@ void sco_collect_examples(int n_envs, const uint8_t *events, uint8_t *prev_in, u
 }
 
 /* ------------------------------------------------------------------ SPEC §6: logistic regression */
+int sco_block_envs(void) { return g_block_envs; }
+
 float sco_sigmoid(float z) {
     const float LOG2E = 0x1.715476p+0f, LN2HI = 0x1.63p-1f, LN2LO = -0x1.bd0106p-13f;
     const float E2 = 0x1p-1f, E3 = 0x1.555556p-3f, E4 = 0x1.555556p-5f, E5 = 0x1.111112p-7f,

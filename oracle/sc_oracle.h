@@ -18,7 +18,9 @@ extern "C" {
 
 #define SCO_NACT 5
 #define SCO_NF 1296
-#define SCO_BLOCK_ENVS 256          /* SPEC §5: envs per block */
+#ifndef SCO_BLOCK_ENVS
+#define SCO_BLOCK_ENVS 256          /* SPEC §5: envs per block (64 / 128: the small-batch experiment of DESIGN §10) */
+#endif
 #define SCO_CLF_STRIDE 8
 
 typedef struct {
@@ -50,6 +52,7 @@ typedef struct {
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void sco_sincospi(float t, float *c, float *s);
 float sco_sigmoid(float z);
+int sco_block_envs(void);            /* the SPEC §5 block size this build of the checker was compiled for */
 
 /* SPEC §1.3 for n independent envs with given actions; no reset, no bookkeeping. */
 void sco_pinball_step(const sco_params *p, int n, float *x, float *y, float *vx, float *vy,

@@ -43,6 +43,7 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_libs = {}
 
 
 def lib() -> C.CDLL:
@@ -53,7 +54,30 @@ def lib() -> C.CDLL:
         _lib.sco_sigmoid.restype = C.c_float
         _lib.sco_sigmoid.argtypes = [C.c_float]
         _lib.sco_q_update_grad.restype = C.c_int
+        _libs[LIB_PATH] = _lib
     return _lib
+
+
+def use_block_envs(block_envs: int = 256) -> None:
+    """Point the checker at its build for another SPEC §5 block size (64 / 128 / 256: the HIP library is built for the same
+    three, and each is checked against the oracle of its own geometry)."""
+    global _lib, BLOCK_ENVS
+    if os.environ.get("SCO_LIB") and block_envs == 256:
+        path = LIB_PATH
+    else:
+        path = os.path.join(_HERE, "libsc_oracle.so" if block_envs == 256 else f"libsc_oracle_b{block_envs}.so")
+    if path not in _libs:
+        build()
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", _HERE, "-s", os.path.basename(path)], check=True, capture_output=True)
+        l = C.CDLL(path)
+        l.sco_sigmoid.restype = C.c_float
+        l.sco_sigmoid.argtypes = [C.c_float]
+        l.sco_q_update_grad.restype = C.c_int
+        assert l.sco_block_envs() == block_envs, (path, l.sco_block_envs())
+        _libs[path] = l
+    _lib = _libs[path]
+    BLOCK_ENVS = block_envs
 
 
 def _p(a):

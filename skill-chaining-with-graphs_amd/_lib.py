@@ -82,42 +82,58 @@ _SIGS = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
-_lib = None
+BLOCK_ENVS_DEFAULT = 256
+BLOCK_ENVS_BUILDS = (64, 128, 256)     # SPEC §5 geometry is a build parameter: csrc/Makefile builds one library per value
+
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """Load libscg_hip.so (once). Raises ScgError loudly when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib_path(block_envs: int | None = None) -> str:
+    """The library of a block geometry: libscg_hip.so (256 envs per block = per workgroup, the throughput build) or
+    libscg_hip_b64.so / _b128.so (the small-batch builds). SCG_LIB overrides the default build only."""
+    if block_envs in (None, BLOCK_ENVS_DEFAULT):
+        return LIB_PATH
+    if block_envs not in BLOCK_ENVS_BUILDS:
+        raise ScgError(f"block_envs must be one of {BLOCK_ENVS_BUILDS}")
+    return os.path.join(_HERE, "csrc", f"libscg_hip_b{block_envs}.so")
+
+
+def load(block_envs: int | None = None) -> C.CDLL:
+    """Load the HIP library of a block geometry (once each). Raises ScgError loudly when it has not been built."""
+    key = BLOCK_ENVS_DEFAULT if block_envs is None else int(block_envs)
+    if key in _libs:
+        return _libs[key]
+    path = lib_path(key)
+    if not os.path.exists(path):
         raise ScgError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            f"{path} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
-            f"{os.path.dirname(LIB_PATH)}`). There is no CPU fallback."
+            f"{os.path.dirname(path)}`). There is no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     try:
         ver = int(lib.scg_abi_version())
     except AttributeError:
-        raise ScgError(f"{LIB_PATH} does not export scg_abi_version: not a libscg_hip.so") from None
+        raise ScgError(f"{path} does not export scg_abi_version: not a libscg_hip.so") from None
     if ver != ABI_VERSION:
-        raise ScgError(f"{LIB_PATH} implements ABI version {ver}, this binding expects {ABI_VERSION} "
+        raise ScgError(f"{path} implements ABI version {ver}, this binding expects {ABI_VERSION} "
                        "(include/scg_abi.h): rebuild the library (a stale .so?)")
     for name, (res, args) in _SIGS.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            raise ScgError(f"{LIB_PATH} does not export {name} although it reports ABI version {ver}: rebuild it") from None
+            raise ScgError(f"{path} does not export {name} although it reports ABI version {ver}: rebuild it") from None
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if block_envs is not None and int(lib.scg_block_envs()) != key:
+        raise ScgError(f"{path} is built for {int(lib.scg_block_envs())}-env blocks, not {key}: rebuild it")
+    _libs[key] = lib
     return lib
 
 
-def block_envs() -> int:
-    """SPEC §5 block size of the loaded library (envs whose update items share one accumulation chain)."""
-    return int(load().scg_block_envs())
+def block_envs(block_envs: int | None = None) -> int:
+    """SPEC §5 block size of a loaded library (envs whose update items share one accumulation chain)."""
+    return int(load(block_envs).scg_block_envs())
 
 
 def check(status: int, ctx=None, what: str = "") -> None:

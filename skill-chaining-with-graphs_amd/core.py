@@ -38,12 +38,13 @@ class ScgContext:
     def __init__(self, n_envs: int, n_options: int, pmap: PinballMap, *, device: int = 0, seed: int = 0,
                  env_id_base: int = 0, gamma: float = 0.99, alpha: float = 1e-3, epsilon: float = 0.05,
                  r_option_success: float = 10000.0, max_episode_steps: int = 10000,
-                 max_option_steps: int = 250):
+                 max_option_steps: int = 250, block_envs: Optional[int] = None):
         if not torch.cuda.is_available():
             raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")
         if not (0 <= n_options <= MAX_OPTIONS):
             raise ScgError(f"n_options must be in [0, {MAX_OPTIONS}]")
-        self.lib = _lib.load()
+        self.lib = _lib.load(block_envs)                     # None: the 256-env build; 64 / 128: the small-batch builds (SPEC §5 geometry)
+        self.block_envs = int(self.lib.scg_block_envs())
         self.n_envs, self.n_options, self.n_vf = int(n_envs), int(n_options), int(n_options) + 1
         self.device = torch.device("cuda", device)
         self.map = pmap

@@ -10,7 +10,10 @@ namespace scg {
 
 constexpr int NACT = 5;
 constexpr int NF = 1296;
-constexpr int BLOCK_ENVS = 256;               // SPEC §5 geometry: envs per block = per workgroup
+#ifndef SCG_BLOCK_ENVS
+#define SCG_BLOCK_ENVS 256     // (build parameter for the small-batch experiment of DESIGN §10: 64 / 128; the oracle follows by SCO_BLOCK_ENVS)
+#endif
+constexpr int BLOCK_ENVS = SCG_BLOCK_ENVS;    // SPEC §5 geometry: envs per block = per workgroup
 constexpr int WAVES = 16;                     // wavefronts per workgroup (one workgroup per CU: four waves per SIMD)
 constexpr int LIST_WAVES = BLOCK_ENVS / 64;   // waves that ballot the workgroup's env flags
 constexpr int THREADS = WAVES * 64;

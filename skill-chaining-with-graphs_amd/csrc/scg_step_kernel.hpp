@@ -14,13 +14,13 @@
 //            (T = W (180 x 36, A operands streamed from LDS) x [Re CD | Im CD]); the few envs ENTERING the block's
 //            option from outside the prefix are compacted into extra column blocks
 //   U2       chunks of 144 padded slots of the root's update list (sorted by action, position): one build per slot gives
-//            CDT (shared), PT_0 = delta_0 ABsel and, for the prefix slots, PT_k = delta_k ABsel; the 90 output tiles
-//            (2 value functions x 5 actions x 9) are dealt to the 16 waves, accumulators stay in registers for the pass
+//            CDT (shared), PT_0 = delta_0 ABsel and, for the prefix slots, PT_k = delta_k ABsel; wave w < 15 owns
+//            the three output tiles (mi = w % 3, ni = 0..2) of action w / 3 of BOTH value functions, in registers for the pass
 //   Because an option's items are a prefix of every action run of the root's list, its groups of four are the root's
 //   groups of four: the accumulation order of SPEC §5 is reproduced exactly (null items masked to +0 on both operands).
 // Value functions with update items that are NOT that prefix (gestating options, a second option in the padded env
 // order) take a single-VF pass of their own afterwards (compacted lists, as in rounds 2-3); value functions that only
-// have envs entering them are evaluated on the vector pipe in the tail. MODE_TRANS / MODE_QVAL are single passes.
+// have envs entering them are evaluated as extra E units of pass 0 (operands from memory). MODE_TRANS / MODE_QVAL are single passes.
 // Every sum has the pinned order of SPEC §3.1 / §5 (no atomics on data): the CPU oracle reproduces every bit.
 #pragma once
 
@@ -89,17 +89,9 @@ constexpr int M_INTS = 128;
 static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
-// wave priorities (s_setprio), build-time knobs for tools/ab_bench.py
-// Evaluation-only value functions (envs ENTERING an option nobody in the block runs), three builds for tools/ab_bench.py:
-//   default       extra E units of pass 0, A operands straight from W_k in memory (contract_g)
-//   SCG_EO_MFMA   behind the passes: up to four W_k staged side by side, one wave per slot, E units from LDS
-//   SCG_EO_VALU   on the vector pipe behind each wave's E units (rounds 2-3), [SCG_EO_VALU_COALESCED: rows through LDS]
-#if !defined(SCG_EO_MFMA) && !defined(SCG_EO_VALU)
-#define SCG_EO_UNITS 1
-#endif
-#if !defined(SCG_E_STATIC)
-#define SCG_E_DYN 1           // E units taken from an LDS counter (737.2 vs 731.5 M env-steps/s against the static deal)
-#endif
+// Build-time knobs for tools/ab_bench.py (the variants measured and dropped in round 4 — evaluation-only value functions on the
+// vector pipe or behind the passes, static deals of E's and U1's units, E rebalancing — are kept as
+// profiles/r04_dropped_kernel_variants.diff with their numbers in profiles/r04_td_kernel_ab_log.txt).
 #ifndef SCG_E_TG
 #define SCG_E_TG 4            // row tiles per operand group of the LDS-fed contraction (12 % SCG_E_TG == 0)
 #endif
@@ -647,12 +639,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 // one atomic per distinct (row, option id) of the wave instead of one per env: neighbours in the env order are
                 // neighbours in env id, so a wave holds about ten distinct keys — six times fewer atomics on 2048 hot counters, whose
                 // acknowledgements every later s_waitcnt vmcnt of this wave has to sit out
-#ifdef SCG_NO_HISTAGG
-                if (hkey >= 0) atomicAdd(&A.hist_next[hkey], 1);
-                uint64_t rem = 0;
-#else
                 uint64_t rem = __ballot(hkey >= 0);
-#endif
                 while (rem) {
                     const int src = (int)__builtin_ctzll(rem);
                     const int k0 = __shfl(hkey, src, 64);
@@ -757,11 +744,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
         SCG_HSTAMP(14);
-#ifdef SCG_U1_STATIC
-        run_u1(hw, N_HELP, 0);
-#else
         run_u1_dyn();
-#endif
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
@@ -818,11 +801,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             kA = __builtin_ctz(single); single &= single - 1; kBp = -1; dense = false;
         }
         const bool u1_done = helpers && pass == 0;          // the helper waves ran U1 and built the list under phase P
-#ifdef SCG_PASS0_BARRIER
-        block_lds_sync();
-#else
         if (pass > 0) block_lds_sync();                     // (pass 0 starts behind the barrier that ends phase P)
-#endif
         SCG_STAMP(pass == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
         // ---- per-env flags of the pass (SPEC §5): ev bit v = the env needs Q_v(s_next, .) (bootstrap target and/or next
         // action); update items of A (all of them in pass 0 of a fused step: the root updates on every env) with their action
@@ -857,24 +836,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         // compacted list: single passes -> the eval items of A; pass 0 -> the envs that need Q_B but lie outside B's prefix groups
         const int pg_b = (mB + 7) >> 3;                     // position groups that hold B's prefix
         const bool cmp = dense ? (evB && (ft >> 3) >= pg_b) : evA;
-#ifdef SCG_EO_UNITS
         const bool eo_pass = pass == 0 && MODE == MODE_FUSED && eval_only != 0;
         const int on_me = (unsigned)ft < (unsigned)nb ? (int)s_on[ft] : 0;
         const bool eo = eo_pass && (unsigned)ft < (unsigned)nb && ((eval_only >> (on_me & 7)) & 1u);       // this env enters an evaluation-only value function
         uint64_t me[MAX_VF];
-#endif
         if (ft == 0) s_misc[M_ECTR] = 0;
         uint64_t mb[1 + NACT];
         if ((unsigned)lw < (unsigned)LIST_WAVES) {
             mb[0] = __ballot(cmp);
-#ifdef SCG_EO_UNITS
 #pragma unroll
             for (int k = 1; k < MAX_VF; ++k) me[k] = eo_pass ? __ballot(eo && on_me == k) : 0ull;
             if (lane >= 11 && lane < 10 + MAX_VF) {                                       // counts per value function: slots 11..15
                 const int k = lane - 10;
                 s_misc[M_CNT + lw * 16 + lane] = __popcll(k == 1 ? me[1] : k == 2 ? me[2] : k == 3 ? me[3] : k == 4 ? me[4] : me[5]);
             }
-#endif
 #pragma unroll
             for (int a = 0; a < NACT; ++a) mb[1 + a] = __ballot(up && at == a);
             const int lim = (kBp >= 1 ? mB : 0) - 64 * lw;                          // positions below mB belong to option kB
@@ -928,7 +903,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         int eo_cnt[MAX_VF], eo_base[MAX_VF], eo_units_l = 0;
 #pragma unroll
         for (int k = 0; k < MAX_VF; ++k) { eo_cnt[k] = 0; eo_base[k] = 0; }
-#ifdef SCG_EO_UNITS
         if (eo_pass && (unsigned)lw < (unsigned)LIST_WAVES) {
             int base = (n_cmp + 7) & ~7;
 #pragma unroll
@@ -947,10 +921,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 s_misc[M_EO + 6 + k] = k == 0 ? eo_units_l : k == 1 ? eo_base[1] : k == 2 ? eo_base[2] : k == 3 ? eo_base[3] : k == 4 ? eo_base[4] : eo_base[5];
             }
         }
-#endif
         if ((unsigned)lw < (unsigned)LIST_WAVES) {
             const uint64_t below = (1ull << lane) - 1ull;
-#ifdef SCG_EO_UNITS
             if (eo) {
                 int off = 0;
                 for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16 + 10 + on_me];
@@ -958,7 +930,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 const int eb = on_me == 1 ? eo_base[1] : on_me == 2 ? eo_base[2] : on_me == 3 ? eo_base[3] : on_me == 4 ? eo_base[4] : eo_base[5];
                 s_elist[eb + off + __popcll(mine & below)] = (uint16_t)ft;
             }
-#endif
             if (cmp) {
                 int off = 0;
                 for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16];
@@ -982,51 +953,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         // the compacted list.
         const int npg = dense ? (nb + 7) >> 3 : 0;
         const int n_own = (n_cmp + 7) >> 3;                 // units of the pass's own compacted list
-#ifdef SCG_EO_UNITS
         const int eo_units = eo_pass ? __builtin_amdgcn_readfirstlane(s_misc[M_EO + 6]) : 0;
-#else
-        const int eo_units = 0;
-#endif
         const int n_units = npg + n_own + eo_units;
         if (n_units + nupd == 0) continue;
-#ifdef SCG_PRIO_E_YOUNG
-        if (helpers && pass == 0) { if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(SCG_PRIO_E_YOUNG); else __builtin_amdgcn_s_setprio(0); }   // (A/B knob: the younger half of every SIMD first)
-#endif
         {
 #ifdef SCG_STAMPS
         const unsigned long long e_t0 = __builtin_amdgcn_s_memtime();
 #endif
-        // Dealing. Compacted units (the pass's own compacted list, then the evaluation-only value functions') go to the waves
-        // from the top down: unit c to wave 15 - c % 16. Position groups go to the waves from the bottom up, group j to wave
-        // j % 16 — except that a top wave holding a compacted unit (an evaluation-only unit waits on memory for its operands
-        // and costs about two LDS-fed evaluations) hands its SECOND position group (j = 16 + w, a single evaluation in the
-        // sorted order: the groups behind the option's prefix) to one of the waves below, which hold only three evaluations:
-        // measured per wave, the four top waves used to finish 15k cycles after everybody else.
+        // Dealing: units are taken from a counter in LDS by whichever wave is free (a static deal left the four top waves —
+        // the youngest of their SIMDs — 15k cycles behind the others). Order: the compacted units first (the pass's own list,
+        // then the evaluation-only value functions', which wait on memory for their operands and want LDS-fed units beside
+        // them), then the position groups in order — the option's prefix (two evaluations each) before the groups behind it
+        // (one): the big items first, the small ones fill the end. (Letting the position groups start before the lists are
+        // written — an LDS counter instead of the barrier above — measured 750.6 against 749.6 M env-steps/s: not kept.)
         const int n_cu = n_own + eo_units;
-#ifdef SCG_REBAL
-        const int n_t = (dense && n_cu <= WAVES / 2 && npg > WAVES) ? n_cu : 0;   // top waves that give their second group away
-#else
-        const int n_t = 0;                                   // (measured: 735 vs 744 M env-steps/s with the hand-over — the top waves are slow
-#endif                                                       //  whatever they hold: they are the youngest of their SIMDs)
-        int my_du[3];
-        int my_dense = 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) my_du[r] = -1;
-        if (n_t == 0) {                                      // plain round robin
-            my_dense = npg > wave ? (npg - wave + WAVES - 1) / WAVES : 0;
-        } else {
-            if (wave < npg) my_du[my_dense++] = wave;
-            if (wave < WAVES - n_t && wave + WAVES < npg) my_du[my_dense++] = wave + WAVES;
-            if (wave >= WAVES - 2 * n_t && wave < WAVES - n_t && wave + WAVES + n_t < npg) my_du[my_dense++] = wave + WAVES + n_t;
-        }
-        const int my_cu = n_cu > WAVES - 1 - wave ? (n_cu - (WAVES - 1 - wave) + WAVES - 1) / WAVES : 0;
-        // (compacted units first: the ones of evaluation-only value functions wait on memory for their operands, which the
-        //  other waves' LDS-fed units cover; a wave that ends on one leaves the matrix pipe idle)
-#ifdef SCG_E_DYN
-        // units are taken from a counter in LDS by whichever wave is free: the compacted units first (the evaluation-only ones
-        // wait on memory for their operands), then the position groups in order — the option's prefix (two evaluations each)
-        // before the groups behind it (one): the big items first, the small ones fill the end
-        (void)my_dense; (void)my_cu; (void)my_du;
         for (;;) {
             int it = 0;
             if (lane == 0) it = atomicAdd(&s_misc[M_ECTR], 1);
@@ -1034,13 +974,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             if (it >= n_cu + npg) break;
             const bool du = it >= n_cu;
             const int u = du ? it - n_cu : it;
-#else
-        for (int it = 0; it < my_dense + my_cu; ++it) {
-            const bool du = it >= my_cu;
-            const int di = it - my_cu;
-            const int u = du ? (n_t == 0 ? wave + WAVES * di : (di == 0 ? my_du[0] : di == 1 ? my_du[1] : my_du[2]))
-                             : (WAVES - 1 - wave) + WAVES * it;                                       // position group / compacted unit
-#endif
             int base, cnt, kg = -1;                          // kg >= 1: unit of evaluation-only value function kg (operands from memory)
             unsigned fl;
             if (du) { base = 8 * u; cnt = min(8, nb - base); fl = (unsigned)__builtin_amdgcn_readfirstlane((int)s_eflag[u]); }
@@ -1110,143 +1043,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #endif
         }
         SCG_STAMP(pass == 0 ? 3 : 10);   // E (wave 0's share)
-#ifdef SCG_EO_VALU
-        // ---- evaluation-only value functions, on the vector pipe, behind this wave's E units (pass 0): Q_k(s_next, .) of the
-        // envs ENTERING an option nobody in this block runs (about 14 (value function, env) pairs per block on the bench workload).
-        // The pairs are enumerated in a fixed order by every wave and dealt from the top wave down (the low waves hold one E
-        // unit more); a wave evaluates its pair alone — the same fmaf chains as the MFMA (SPEC §3.1), so bit-identical to what a
-        // pass would have produced — with its private table area as scratch: no staging of W_k for the workgroup, no lists, no
-        // workgroup barrier. One lane owns one row of W_k (its 36-term chain is sequential); the rows come in through LDS:
-        // 16 rows = 2304 contiguous bytes per piece, read as coalesced 16-byte loads and handed to their lanes by conflict-free
-        // ds_read_b128 (row stride 36 dwords). Read per lane straight from memory (rounds 2-3: one 144-byte row per lane, 64
-        // different cache lines per load instruction) the 14 pairs of a CU kept its one texture path busy for ~19k cycles.
-        if (pass == 0 && MODE == MODE_FUSED && eval_only) {
-            SCG_STAMP(26);
-            float *tb = s_R + R_TAB + wave * E_TAB_FLOATS;
-            float2 *t_ab = reinterpret_cast<float2 *>(tb), *t_cd = t_ab + 36, *t_T = t_cd + 36;      // 36 + 36 + 180 float2
-            f4v *stage = reinterpret_cast<f4v *>(tb + 2 * (36 + 36 + 180));                         // 16 rows x 9 float4
-            static_assert(2 * (36 + 36 + 180) + 16 * 36 <= E_TAB_FLOATS && (2 * (36 + 36 + 180)) % 4 == 0, "pair scratch fits the wave's table area");
-            int pair = 0;
-            for (int k = 1; k < A.n_vf; ++k) {
-                if (!((eval_only >> k) & 1u)) continue;
-                const f4v *Wk4 = reinterpret_cast<const f4v *>(A.W + (size_t)k * NACT * NF);
-                for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
-                    const int ii = 64 * h + lane;
-                    uint64_t m = __ballot(ii < nb && s_on[ii] == k);
-                    while (m) {
-                        const int il = 64 * h + (int)__builtin_ctzll(m);
-                        m &= m - 1;
-#ifdef SCG_STAMPS
-                        if (tid == 0 && A.stamps) s_stamp[30] += 1;                         // (diagnostic) pairs in this block
-#endif
-                        if ((WAVES - 1 - (pair++ & (WAVES - 1))) != wave) continue;      // dealt from the top: the low waves hold more E units
-#ifdef SCG_STAMPS
-                        if (tid == 0 && A.stamps) s_stamp[29] += 1;                         // (diagnostic) ... of which wave 0 took
-#endif
-                        // tables of s_next: lane c < 36 owns AB[c] and CD[c] (c = 6 hi + lo)
-                        if (lane < 36) {
-                            const float4 *zp = reinterpret_cast<const float4 *>(s_z1 + (il * 2 + 1) * 4);
-                            const float4 za = zp[0], zc = zp[1];
-                            const int hi = (lane * 43) >> 8, lo = lane - 6 * hi;                  // lane / 6, lane % 6 for lane < 36
-                            float2 ab = zpow_sel(make_float2(za.z, za.w), lo), cd = zpow_sel(make_float2(zc.z, zc.w), lo);
-#pragma unroll
-                            for (int c = 1; c < 6; ++c) {                                         // row hi: hi chained products
-                                const float2 abn = cmul(ab, make_float2(za.x, za.y)), cdn = cmul(cd, make_float2(zc.x, zc.y));
-                                if (c <= hi) { ab = abn; cd = cdn; }
-                            }
-                            t_ab[lane] = make_float2(ab.x, -ab.y);
-                            t_cd[lane] = cd;
-                        }
-                        // T[row][re | im], row = 36 a + c12: the fmaf chain over c34 = 9 g + kb (kb outer, g inner)
-#pragma unroll 1
-                        for (int r0 = 0; r0 < 192; r0 += 64) {
-                            float wv[36];
-#pragma unroll
-                            for (int q = 0; q < 36; ++q) wv[q] = 0.0f;
-#ifdef SCG_EO_VALU_COALESCED
-                            {   // the round's 64 rows = 9216 contiguous bytes: nine coalesced 1-KB loads, all in flight together ...
-                                const int nf4r = 9 * max(0, min(64, NACT * 36 - r0));             // float4s of the round (<= 576)
-                                f4v ld[9];
-#pragma unroll
-                                for (int j = 0; j < 9; ++j) {
-                                    const int f4i = lane + 64 * j;
-                                    ld[j] = f4i < nf4r ? Wk4[r0 * 9 + f4i] : (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-                                }
-                                // ... then handed to their lanes 16 rows (144 float4s = 2304 bytes of scratch) at a time
-#pragma unroll
-                                for (int pc = 0; pc < 4; ++pc) {
-                                    wave_lds_sync();                                              // (the previous piece is read out)
-#pragma unroll
-                                    for (int j = 0; j < 9; ++j) {
-                                        if (64 * j + 63 >= 144 * pc && 64 * j < 144 * (pc + 1)) {     // (static) load j overlaps piece pc
-                                            const int f4p = 64 * j + lane - 144 * pc;
-                                            if (f4p >= 0 && f4p < 144) stage[f4p] = ld[j];
-                                        }
-                                    }
-                                    wave_lds_sync();
-                                    if ((lane >> 4) == pc) {
-#pragma unroll
-                                        for (int q4 = 0; q4 < 9; ++q4) {
-                                            const f4v w = stage[(lane & 15) * 9 + q4];
-                                            wv[4 * q4] = w[0]; wv[4 * q4 + 1] = w[1]; wv[4 * q4 + 2] = w[2]; wv[4 * q4 + 3] = w[3];
-                                        }
-                                    }
-                                }
-                            }
-#else
-                            if (r0 + lane < NACT * 36) {                                      // one 144-byte row per lane, straight from memory
-                                const f4v *wr = Wk4 + (r0 + lane) * 9;
-#pragma unroll
-                                for (int q4 = 0; q4 < 9; ++q4) {
-                                    const f4v w = wr[q4];
-                                    wv[4 * q4] = w[0]; wv[4 * q4 + 1] = w[1]; wv[4 * q4 + 2] = w[2]; wv[4 * q4 + 3] = w[3];
-                                }
-                            }
-#endif
-                            const int row = r0 + lane;
-                            float tre = 0.0f, tim = 0.0f;
-#pragma unroll
-                            for (int kb = 0; kb < 9; ++kb) {
-#pragma unroll
-                                for (int gg = 0; gg < 4; ++gg) {
-                                    const float2 cdv = t_cd[9 * gg + kb];
-                                    tre = fmaf(wv[9 * gg + kb], cdv.x, tre);
-                                    tim = fmaf(wv[9 * gg + kb], cdv.y, tim);
-                                }
-                            }
-                            if (row < NACT * 36) t_T[row] = make_float2(tre, tim);
-                        }
-                        wave_lds_sync();
-                        // q[a][g][part]: lane = 8 a + 2 g + part chains over its nine c12 in increasing order, then the tree
-                        float qv = 0.0f;
-                        {
-                            const int a = min(lane >> 3, NACT - 1), gq = (lane >> 1) & 3, part = lane & 1;
-                            // rows 36 a + c12 of group gq: c12 = 4 i + v with ((36 a) / 4 + i) % 4 == gq  ->  i = (gq - 9 a) & 3, + 4, + 8
-                            const int i0 = (gq - 9 * a) & 3;
-#pragma unroll
-                            for (int ii3 = 0; ii3 < 3; ++ii3) {
-                                const int i = i0 + 4 * ii3;                                  // i = 0..8: quad of rows 4 i .. 4 i + 3
-                                if (i < 9) {
-#pragma unroll
-                                    for (int v = 0; v < 4; ++v) {
-                                        const float2 tv = t_T[36 * a + 4 * i + v], av = t_ab[4 * i + v];
-                                        qv = fmaf(part ? tv.y : tv.x, part ? av.y : av.x, qv);
-                                    }
-                                }
-                            }
-                        }
-                        qv = qv + __shfl_xor(qv, 1, 64);                      // u_g = q_re + q_im
-                        qv = qv + __shfl_xor(qv, 2, 64);                      // u_0 + u_1 | u_2 + u_3
-                        qv = qv + __shfl_xor(qv, 4, 64);                      // (u_0 + u_1) + (u_2 + u_3)
-                        if (lane < 8 * NACT && (lane & 7) == 0)               // into the env's result line (orec[2].xyzw, orec[3].x)
-                            reinterpret_cast<float *>(A.outrec + (size_t)(e0 + il) * 4)[8 + (lane >> 3)] = qv;
-                        wave_lds_sync();
-                    }
-                }
-            }
-            SCG_STAMP(27);
-        }
-#endif
         // ---- U1 (pass 0 of a learning step: ran under phase P on the helper waves)
         if (MODE != MODE_QVAL && nupd > 0 && !u1_done) run_u1(wave, WAVES, n_units);   // dealt on behind E's blocks
         if (MODE == MODE_QVAL || nupd == 0) continue;
@@ -1356,6 +1152,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         };
         auto u2_mfma = [&](int ch, const float *tab) {
             if (!worker) return;
+#ifdef SCG_DIAG_FREE_BORDER         // (diagnostic, WRONG results: prices U2's five border tiles at zero — the ceiling of "border tiles on the vector pipe")
+            if (jm == 2) return;
+#endif
             int gb[NACT], gc[NACT], co[NACT + 1];
             chunk_geo(ch, gb, gc, co);
             const float *ptabA = tab, *ptabB = tab + 36 * USX, *ctab = tab + 2 * 36 * USX;
@@ -1373,10 +1172,14 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                        c2 = *reinterpret_cast<const float2 *>(pb2 + 8 * gi);
                 accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, a2.x, accU[0][0], 0, 0, 0);
                 accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, a2.x, accU[0][1], 0, 0, 0);
+#ifndef SCG_DIAG_FREE_BORDER
                 accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, a2.x, accU[0][2], 0, 0, 0);
+#endif
                 accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, a2.y, accU[0][0], 0, 0, 0);
                 accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, a2.y, accU[0][1], 0, 0, 0);
+#ifndef SCG_DIAG_FREE_BORDER
                 accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, a2.y, accU[0][2], 0, 0, 0);
+#endif
                 if (gi < ngrpB) {
                     const float2 b2 = *reinterpret_cast<const float2 *>(paB + 8 * gi);
                     if (4 * gi + 4 > nvalid && 4 * gi + g >= nvalid) {            // null item of B: both operands +0 (SPEC §5)
@@ -1384,10 +1187,14 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     }
                     accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, b2.x, accU[1][0], 0, 0, 0);
                     accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, b2.x, accU[1][1], 0, 0, 0);
+#ifndef SCG_DIAG_FREE_BORDER
                     accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, b2.x, accU[1][2], 0, 0, 0);
+#endif
                     accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, b2.y, accU[1][0], 0, 0, 0);
                     accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b2.y, accU[1][1], 0, 0, 0);
+#ifndef SCG_DIAG_FREE_BORDER
                     accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, b2.y, accU[1][2], 0, 0, 0);
+#endif
                 }
             }
         };
@@ -1425,89 +1232,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(15);                // slab stores issued
     }
-    // ------------------------------------------------------------------ evaluation-only value functions
-    // Q_k(s_next, .) of the envs ENTERING an option nobody in this block runs (about 14 (value function, env) pairs per block on
-    // the bench workload, over 2-4 value functions). Behind the passes region R is free: the weights of up to EO_SLOTS such
-    // value functions are staged side by side (one coalesced read each), then one wave per slot — waves 0, 4, 8, 12: one per
-    // SIMD — compacts its value function's envs eight at a time and evaluates them as ordinary E units on the matrix pipe:
-    // bit-identical to a pass by construction, one barrier pair per round of EO_SLOTS value functions. (Rounds 2-3 evaluated
-    // every pair on the vector pipe with W_k rows read per lane from global memory: with one workgroup per CU those strided
-    // 16-byte gathers — 27 KB per pair through the CU's one texture path — were 19k cycles of nobody's time but this wave's.)
-#ifdef SCG_EO_MFMA
-    if (MODE == MODE_FUSED && eval_only) {
-        constexpr int EO_SLOTS = 4;
-        static_assert(EO_SLOTS * (W_FLOATS + E_TAB_FLOATS) <= R_FLOATS && EO_SLOTS * 4 <= WAVES, "slots fit region R");
-        unsigned todo = eval_only;
-        while (todo) {
-            int lane_e;                                     // (opaque per round, as in the pass loop: no hoisting, no spills)
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-            const int tid = (wave << 6) | lane_e, lane = lane_e;
-            int ks[EO_SLOTS];
-            int ns = 0;
-#pragma unroll
-            for (int sl = 0; sl < EO_SLOTS; ++sl) {
-                ks[sl] = todo ? __builtin_ctz(todo) : 0;
-                if (todo) { ++ns; todo &= todo - 1; }
-            }
-            block_lds_sync();                               // region R is free (the last U2 chunk / the previous round is consumed)
-            SCG_STAMP(26);
-#pragma unroll
-            for (int sl = 0; sl < EO_SLOTS; ++sl)
-                if (sl < ns) stage_w(A.W + (size_t)ks[sl] * NACT * NF, sl * W_FLOATS, tid, THREADS);
-            SCG_STAMP(8);
-            block_lds_sync();
-            SCG_STAMP(31);
-            if ((wave & 3) == 0 && (wave >> 2) < ns) {
-                const int sl = wave >> 2;
-                const int k = sl == 0 ? ks[0] : sl == 1 ? ks[1] : sl == 2 ? ks[2] : ks[3];
-                int lane_r = lane;
-                asm volatile("" : "+v"(lane_r));
-                const int n16 = lane_r & 15, g = lane_r >> 4, bi = lane_r & 7, cp = lane_r >> 3;
-                const int bcol = 8 * (bi >> 2) + (bi & 3), ocol_item = 4 * (n16 >> 3) + (n16 & 3);
-                const bool out_lane = (g == 0) && !(n16 & 4);
-                float *cdk = s_R + EO_SLOTS * W_FLOATS + sl * E_TAB_FLOATS, *abq = cdk + 36 * 16;
-                const float *ab_lane = abq + n16 * AS + 4 * g;
-                const f4v *w4 = reinterpret_cast<const f4v *>(s_W) + lane_r;
-                const float *w8 = s_W + W_TAIL + lane_r;
-                uint16_t *slot8 = s_elist + 8 * sl;         // the unit's items (positions), written by the lanes that own them
-                uint64_t mk[BLOCK_ENVS / 64];
-                int total = 0;
-#pragma unroll
-                for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
-                    mk[h] = __ballot(64 * h + lane_r < nb && s_on[64 * h + lane_r] == k);
-                    total += __popcll(mk[h]);
-                }
-                const uint64_t below = (1ull << lane_r) - 1ull;
-                for (int u0 = 0; u0 < total; u0 += 8) {
-                    const int cnt = min(8, total - u0);
-                    int before = 0;
-#pragma unroll
-                    for (int h = 0; h < BLOCK_ENVS / 64; ++h) {
-                        const int r = before + __popcll(mk[h] & below) - u0;             // rank of this lane's env among the entering ones
-                        if (((mk[h] >> lane_r) & 1ull) && r >= 0 && r < 8) slot8[r] = (uint16_t)(64 * h + lane_r);
-                        before += __popcll(mk[h]);
-                    }
-                    wave_lds_sync();
-                    build_tables((int)slot8[min(bi, cnt - 1)], 1, cp, bcol, cdk, abq);
-                    const int il = slot8[min(ocol_item, cnt - 1)];
-                    wave_lds_sync();
-                    float B[9];
-#pragma unroll
-                    for (int kb = 0; kb < 9; ++kb) B[kb] = cdk[(9 * g + kb) * 16 + n16];
-                    float qo[NACT];
-                    contract(sl * W_FLOATS, B, qo, n16, g, w4, w8, ab_lane);
-                    if (out_lane && ocol_item < cnt) {      // into the env's result line (orec[2].xyzw, orec[3].x); commit_row writes qcache
-                        float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
-                        orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
-                        orec[3].x = qo[4];
-                    }
-                    wave_lds_sync();
-                }
-            }
-            SCG_STAMP(27);
-        }
-    }
-#endif
     if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)
         block_lds_sync();
         if (tid == 0 && s_misc[M_FAIL])

@@ -12,11 +12,22 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), device="cuda:0")
 
 
+_BLOCK_ENVS = None        # None: the default (256-env) builds of both sides
+
+
+def set_block_envs(block_envs=None):
+    """Every make_pair() from here on pairs the HIP library and the oracle BUILT FOR this SPEC §5 block size (64 / 128 / 256)."""
+    global _BLOCK_ENVS
+    _BLOCK_ENVS = block_envs
+    sc_oracle.use_block_envs(block_envs or 256)
+
+
 def make_pair(map_name, n_envs, n_options=0, seed=0, env_id_base=0, enabled_mask=0, **hp):
     m = scg.load_map(map_name)
     kw = dict(HP)
     kw.update(hp)
-    ctx = ScgContext(n_envs, n_options, m, device=0, seed=seed, env_id_base=env_id_base, **kw)
+    ctx = ScgContext(n_envs, n_options, m, device=0, seed=seed, env_id_base=env_id_base, block_envs=_BLOCK_ENVS, **kw)
+    assert ctx.block_envs == (_BLOCK_ENVS or 256) == sc_oracle.lib().sco_block_envs()
     orc = sc_oracle.Oracle(m, SCALE, n_envs=n_envs, n_options=n_options, seed=seed, env_id_base=env_id_base,
                            enabled_mask=enabled_mask, n_threads=8, **kw)
     return ctx, orc, m

@@ -44,10 +44,31 @@ def test_create_rejects_bad_config_without_touching_a_device(pkg):
 
 def test_missing_library_fails_loudly(pkg, monkeypatch):
     from skill_chaining_with_graphs_amd import _lib
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libscg_hip.so")
     with pytest.raises(_lib.ScgError, match="no CPU fallback"):
         _lib.load()
+    with pytest.raises(_lib.ScgError, match="block_envs must be one of"):
+        _lib.load(96)
+
+
+def test_every_block_geometry_build_exports_the_abi_and_reports_its_block(pkg):
+    """SPEC §5's block size is a build parameter: three libraries from one source, chosen per context (block_envs=...);
+    the checker is built for the same three."""
+    from skill_chaining_with_graphs_amd import _lib
+    from oracle import sc_oracle as O
+    assert _lib.block_envs() == 256
+    try:
+        for b in _lib.BLOCK_ENVS_BUILDS:
+            lib = _lib.load(b)
+            for name in declared_symbols():
+                assert hasattr(lib, name), (b, name)
+            assert lib.scg_block_envs() == b and lib.scg_abi_version() == 2
+            O.use_block_envs(b)
+            assert O.lib().sco_block_envs() == b
+    finally:
+        O.use_block_envs(256)
+    assert _lib.load(256) is _lib.load()
 
 
 def test_product_never_imports_the_oracle():

@@ -53,8 +53,34 @@ def test_committed_bench_lines_carry_the_contract_fields():
     assert with_cpu >= 2                                            # the default and the driver-form line of the final build
 
 
-def test_traffic_file_is_consistent_with_the_pmc_summary():
-    t = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-    assert t["traffic_bytes_per_launch"] == int((2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024)
-    assert abs(t["traffic_over_algorithmic"] - t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"]) < 1e-9
-    assert t["algorithmic_bytes_per_launch"] == 65536 * 46
+def test_traffic_files_are_consistent_with_the_pmc_summary():
+    for name in ("r03_traffic.json", "r04_traffic.json"):
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert t["traffic_bytes_per_launch"] == int((2 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024), name
+        assert abs(t["traffic_over_algorithmic"] - t["traffic_bytes_per_launch"] / t["algorithmic_bytes_per_launch"]) < 1e-9, name
+        assert t["algorithmic_bytes_per_launch"] == 65536 * 46, name
+
+
+def test_bench_reads_the_newest_traffic_file():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'TRAFFIC_FILES = ("r04_traffic.json"' in src
+    assert os.path.exists(os.path.join(ROOT, "profiles", "r04_traffic.json"))
+
+
+def test_round_4_lines_carry_the_extra_measurements():
+    """the small config and the DISCOVERED chain as extra keys beside the headline (which stays as it was)."""
+    seen = 0
+    for name, d in _lines():
+        if not name.startswith("r04_"):
+            continue
+        ex = d.get("extras")
+        assert ex is not None, name
+        c1, dc = ex["config1_4096_envs_root_plus_1_option"], ex["discovered_chain_65536_envs"]
+        assert c1["unit"] == dc["unit"] == "env-steps/s" and c1["workgroups"] == 16 and c1["value"] > 1e7, name
+        assert abs(c1["value"] - 4096 / (c1["us_per_step"] * 1e-6)) < 1e-3 * c1["value"], name
+        assert 1 <= dc["options_created"] <= 5 and len(dc["fit_accuracy"]) == dc["options_created"], name
+        assert sum(dc["envs_per_running_option_at_end"]) == 65536, name
+        assert dc["envs_in_an_option_at_end"] == sum(dc["envs_per_running_option_at_end"][1:]), name
+        assert abs(dc["value"] - 65536 / (dc["us_per_step"] * 1e-6)) < 1e-3 * dc["value"], name
+        seen += 1
+    assert seen >= 2
