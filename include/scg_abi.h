@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 2
+#define SCG_ABI_VERSION 3
 #define SCG_NUM_ACTIONS 5
 #define SCG_FOURIER_ORDER 5
 #define SCG_NUM_FEATURES 1296      /* (order+1)^4 */
@@ -61,7 +61,9 @@ typedef struct {
 #define SCG_STEP_APPLY 2u        /* apply it to W in the same call (single-rank path) */
 
 int scg_abi_version(void);
-int scg_block_envs(void);            /* SPEC §5 block size this library was built with: 256 envs (one 16-wavefront workgroup) */
+int scg_block_envs(void);            /* SPEC §5 block size this library was built with (one 16-wavefront workgroup per block): 256 for libscg_hip.so;
+                                        libscg_hip_b128.so / _b64.so are the same source built for 128 / 64 (small env counts). The block size
+                                        orders the partial sums of G: a sharded run uses ONE geometry on all ranks */
 const char *scg_strerror(int status);
 const char *scg_last_error(const scg_ctx *ctx);
 
@@ -101,6 +103,12 @@ int scg_apply_update(scg_ctx *ctx, float *W, const float *G, const int32_t *n_k,
  * buffers. scg_apply_update_packed reads the counts back from the tail. */
 int scg_set_grad_buffer_packed(scg_ctx *ctx, float *G_packed);
 int scg_apply_update_packed(scg_ctx *ctx, float *W, const float *G_packed, void *stream);
+/* The ORDER-PINNED multi-rank sum (ABI 3): `slots` holds the packed operands of n_slots ranks, slot r at
+ * slots + r * slot_stride floats (slot_stride >= n_vf*6480 + n_vf) — what an all-gather of every rank's G_packed leaves —
+ * and the update is applied from their sum taken IN SLOT ORDER, ((G_0 + G_1) + G_2) + ..., element by element
+ * (SPEC §5): every rank then holds bit-identical weights whatever the rank count, and the CPU oracle reproduces them.
+ * (An all-reduce's order of additions is the library's business: exact for two ranks, to rounding beyond.) */
+int scg_apply_update_slots(scg_ctx *ctx, float *W, const float *slots, int32_t n_slots, int64_t slot_stride, void *stream);
 
 /* ---- un-fused entry points (same arithmetic; used by the API facade and the parity tests) ---- */
 

@@ -17,7 +17,7 @@ CLF_STRIDE = 8
 
 STEP_LEARN = 1
 STEP_APPLY = 2
-ABI_VERSION = int(os.environ.get("SCG_LIB_ABI", "2"))   # include/scg_abi.h SCG_ABI_VERSION (SCG_LIB_ABI: A/B runs against a historical build)
+ABI_VERSION = int(os.environ.get("SCG_LIB_ABI", "3"))   # include/scg_abi.h SCG_ABI_VERSION (SCG_LIB_ABI: A/B runs against a historical build)
 ASYNC_FIT_TIMEOUT = 0x1
 ASYNC_STEP_HANDOFF = 0x2
 
@@ -59,6 +59,7 @@ _SIGS = {
     "scg_apply_update": (C.c_int, [_P, _P, _P, _P, _P]),
     "scg_set_grad_buffer_packed": (C.c_int, [_P, _P]),
     "scg_apply_update_packed": (C.c_int, [_P, _P, _P, _P]),
+    "scg_apply_update_slots": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, _P]),
     "scg_pinball_step": (C.c_int, [_P, C.c_int32] + [_P] * 7 + [_P]),
     "scg_fourier_features": (C.c_int, [_P, C.c_int32] + [_P] * 5 + [_P]),
     "scg_q_values": (C.c_int, [_P, C.c_int32] + [_P] * 6 + [_P]),

@@ -20,7 +20,7 @@ from .pinball import PinballDomain
 
 class SkillChainingAgent:
     def __init__(self, pmap, n_envs: int, n_options: int = 0, *, device: int = 0, seed: int = 0,
-                 env_id_base: int = 0, group=None, **hparams):
+                 env_id_base: int = 0, group=None, ordered_sum: bool = False, **hparams):
         self.map: PinballMap = load_map(pmap) if isinstance(pmap, str) else pmap
         self.ctx = ScgContext(n_envs, n_options, self.map, device=device, seed=seed, env_id_base=env_id_base,
                               **hparams)
@@ -33,6 +33,8 @@ class SkillChainingAgent:
         self._gest_need = {}
         self.t = 0
         self.group = group            # torch.distributed group for shared option-Q weights (or None)
+        self.ordered_sum = bool(ordered_sum)   # shared weights summed in rank order from an all-gather (bit-identical on any
+        self._slots = None                     # rank count, reproduced by the oracle) instead of an all-reduce (exact for two ranks)
         self.allreduce_timing = None  # see time_allreduce()
         self.domain = PinballDomain(self.ctx)
         self.state: EnvState = self.domain.state
@@ -220,11 +222,20 @@ class SkillChainingAgent:
             if sample:                                   # measurement hook (bench.py): events on the stream of use
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            _dist.allreduce_packed(gp, self.group)      # RCCL over xGMI: one latency-bound 26 KB x n_vf message
+            if self.ordered_sum:
+                if self._slots is None:
+                    import torch.distributed as dist
+                    self._slots = torch.zeros((dist.get_world_size(self.group), gp.numel()), dtype=torch.float32, device=gp.device)
+                _dist.allgather_packed(gp, self._slots, self.group)     # one all-gather; the sum is taken in rank order on every rank
+            else:
+                _dist.allreduce_packed(gp, self.group)      # RCCL over xGMI: one latency-bound 26 KB x n_vf message
             if sample:
                 e1.record()
                 timing["events"].append((e0, e1))
-            self.ctx.apply_update_packed(self.W, gp)
+            if self.ordered_sum:
+                self.ctx.apply_update_slots(self.W, self._slots)
+            else:
+                self.ctx.apply_update_packed(self.W, gp)
         self.t += 1
 
     def time_allreduce(self, every: int = 0) -> Optional[dict]:

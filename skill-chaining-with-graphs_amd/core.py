@@ -252,6 +252,17 @@ class ScgContext:
         self._chk(gp, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES + self.n_vf, "G_packed")
         self._call("scg_apply_update_packed", _ptr(W), _ptr(gp), self._stream())
 
+    def apply_update_slots(self, W: torch.Tensor, slots: torch.Tensor) -> None:
+        """The order-pinned multi-rank update (SPEC §5): `slots` [n_ranks, n_vf*5*1296 + n_vf] holds every rank's packed operand
+        (an all-gather of grad_packed()); G and the counts are summed in slot order, so all ranks hold bit-identical weights
+        whatever their number."""
+        per = self.n_vf * NUM_ACTIONS * NUM_FEATURES + self.n_vf
+        if slots.dim() != 2 or slots.shape[1] != per or not slots.is_contiguous():
+            raise ScgError(f"slots must be a contiguous [n_ranks, {per}] tensor")
+        self._chk(W, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
+        self._chk(slots, torch.float32, slots.shape[0] * per, "slots")
+        self._call("scg_apply_update_slots", _ptr(W), _ptr(slots), C.c_int32(slots.shape[0]), C.c_int64(per), self._stream())
+
     def apply_update(self, W: torch.Tensor, G: torch.Tensor, n_k: torch.Tensor) -> None:
         self._chk(W, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
         self._chk(G, torch.float32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "G")

@@ -515,6 +515,25 @@ __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, co
     *w = fmaf(step * scale[f], G[(size_t)k * NACT * NF + i], *w);
 }
 
+// The order-pinned multi-rank form (SPEC §5): G and the counts are the sums of the ranks' packed operands in slot order.
+__global__ __launch_bounds__(256) void apply_slots_kernel(float *W, const float *slots, int n_slots, long stride, int n_vf,
+                                                          const float *scale, float alpha) {
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NACT * NF) return;
+    const size_t at = (size_t)k * NACT * NF + i, cnt_at = (size_t)n_vf * NACT * NF + k;
+    float g = slots[at], nkf = slots[cnt_at];
+    for (int r = 1; r < n_slots; ++r) {
+        g = g + slots[(size_t)r * stride + at];
+        nkf = nkf + slots[(size_t)r * stride + cnt_at];          // counts as floats: exact (far below 2^24)
+    }
+    const int nk = (int)(nkf + 0.5f);
+    if (nk <= 0) return;
+    const float step = alpha / (float)nk;
+    float *w = W + at;
+    *w = fmaf(step * scale[i % NF], g, *w);
+}
+
 // ------------------------------------------------------------------------------------------------
 // SPEC §5 env order: stable counting sort of the envs by option_id (6 keys), two tiny kernels per step.
 // Option-homogeneous workgroups turn five sparse option passes per workgroup into about one dense one.
@@ -1500,6 +1519,20 @@ int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *s
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G_packed,
                        (const int32_t *)nullptr, G_packed + (size_t)c->n_vf * NACT * NF, c->d_scale, c->cfg.alpha);
+    SCG_HIP(c, hipGetLastError());
+    return SCG_OK;
+}
+
+int scg_apply_update_slots(scg_ctx *c, float *W, const float *slots, int32_t n_slots, int64_t slot_stride, void *stream) {
+    if (!c || !W || !slots) return fail(c, SCG_ERR_INVALID, "scg_apply_update_slots: null argument");
+    if (n_slots < 1 || n_slots > 4096 || slot_stride < (int64_t)c->n_vf * NACT * NF + c->n_vf)
+        return fail(c, SCG_ERR_INVALID, "scg_apply_update_slots: n_slots must be in [1, 4096] and slot_stride >= n_vf * 6480 + n_vf floats");
+    if (!c->have_map) return fail(c, SCG_ERR_STATE, "scg_apply_update_slots: scg_set_map has not been called (scale table)");
+    SCG_CHECK_ASYNC(c);
+    SCG_ON_DEVICE(c, "scg_apply_update_slots");
+    dim3 grid((NACT * NF + 255) / 256, c->n_vf);
+    hipLaunchKernelGGL(apply_slots_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, slots, (int)n_slots,
+                       (long)slot_stride, c->n_vf, c->d_scale, c->cfg.alpha);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }

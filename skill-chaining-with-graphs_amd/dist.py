@@ -39,6 +39,18 @@ def allreduce_packed(gp: torch.Tensor, group=None) -> None:
         dist.all_reduce(gp, group=group)
 
 
+def allgather_packed(gp: torch.Tensor, slots: torch.Tensor, group=None) -> None:
+    """Every rank's packed operand into `slots` [world, len(gp)], row r = rank r — the operand of the order-pinned sum
+    (scg_apply_update_slots): ONE all-gather per step instead of the all-reduce; bit-identical weights on every rank count."""
+    import torch.distributed as dist
+    if _via_host(gp, group):
+        sc = torch.empty(slots.numel(), dtype=slots.dtype)
+        dist.all_gather_into_tensor(sc, gp.cpu(), group=group)
+        slots.copy_(sc.view(slots.shape))
+    else:
+        dist.all_gather_into_tensor(slots.view(-1), gp, group=group)      # (the concatenated form: row r = rank r)
+
+
 def allreduce_sum_int(value: int, group, device) -> int:
     """Sum of a host integer over the ranks (loop decisions of the sharded outer loop must agree on every rank)."""
     import torch.distributed as dist

@@ -137,3 +137,109 @@ def test_two_rank_processes_share_weights_through_the_agent(tmp_path):
     # sharded skill discovery: same number of options, same classifier table, same (shared) weights on both ranks
     assert int(r0["n_created"][0]) == int(r1["n_created"][0]) >= 1
     assert np.array_equal(r0["clf"], r1["clf"]) and np.array_equal(r0["W2"], r1["W2"])
+
+
+def test_five_shards_with_the_order_pinned_sum_equal_the_oracles_five_shards():
+    """Beyond two ranks an all-reduce's order of additions is the library's; the order-pinned form (all-gather of the packed
+    operands + scg_apply_update_slots: the sum ((G_0 + G_1) + G_2) + ... element by element) is reproduced by the oracle
+    exactly: five contexts stand in for five ranks, the float32 sums are re-done in numpy in the same order."""
+    R, n = 5, 300                                                    # 300 envs per rank: a ragged second block
+    ranks = [make_pair("pinball_simple", n, n_options=NOPT, seed=SEED, env_id_base=r * n, enabled_mask=MASK) for r in range(R)]
+    m = ranks[0][2]
+    x, y, vx, vy = random_states(m, R * n, 77, vmax=1.0)
+    clf = chain_classifiers(m, NOPT)
+    W_o = random_weights(NOPT + 1, 4, std=0.05)
+    st_o, st_d, W_d, gp = [], [], [], []
+    for r, (ctx, orc, _) in enumerate(ranks):
+        st = sc_oracle.new_state(n, m)
+        sl = slice(r * n, (r + 1) * n)
+        st["x"][:], st["y"][:], st["vx"][:], st["vy"][:] = x[sl], y[sl], vx[sl], vy[sl]
+        st_o.append(st); st_d.append(state_to_device(st, ctx)); W_d.append(dev(W_o.copy())); gp.append(ctx.grad_packed())
+    clf_d = dev(clf)
+    differs_from_other_orders = False
+    for t in range(6):
+        G, cnt = [], []
+        for r, (ctx, orc, _) in enumerate(ranks):
+            g_r, n_r = orc.step(st_o[r], W_o, clf, t)
+            G.append(g_r); cnt.append(n_r)
+            ctx.step(st_d[r], W_d[r].view(-1), clf_d.view(-1), MASK, t, learn=True, apply=False)
+        slots = torch.stack(gp).contiguous()                         # what all_gather_into_tensor leaves on every rank
+        for r, (ctx, _, _) in enumerate(ranks):
+            ctx.apply_update_slots(W_d[r].view(-1), slots)
+        g_sum, n_sum = G[0].copy(), cnt[0].copy()
+        for r in range(1, R):
+            g_sum = (g_sum + G[r]).astype(np.float32)                # float32 additions in rank order
+            n_sum = n_sum + cnt[r]
+        g_rev = G[R - 1].copy()
+        for r in range(R - 2, -1, -1):
+            g_rev = (g_rev + G[r]).astype(np.float32)
+        differs_from_other_orders |= not np.array_equal(g_rev, g_sum)
+        ranks[0][1].apply(W_o, g_sum, n_sum)
+        torch.cuda.synchronize()
+        for r in range(R):
+            assert_state_equal(st_d[r], st_o[r], msg=f"rank {r} step {t}")
+            assert torch.equal(W_d[r], W_d[0])
+        assert np.array_equal(W_d[0].cpu().numpy(), W_o), f"weights differ from the oracle's five-shard result at step {t}"
+    assert differs_from_other_orders                                 # (the order does matter at five ranks: the test can tell)
+
+
+def _rank_main_ordered(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import skill_chaining_with_graphs_amd as scg
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    from util import HP
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = scg.load_map("pinball_simple")
+    n = 300
+    x, y, vx, vy = random_states(m, world * n, 77, vmax=1.0)
+    ag = SkillChainingAgent(m, n, NOPT, device=0, seed=SEED, env_id_base=rank * n, group=dist.group.WORLD, ordered_sum=True, **HP)
+    sl = slice(rank * n, (rank + 1) * n)
+    for name, v in (("x", x), ("y", y), ("vx", vx), ("vy", vy)):
+        getattr(ag.state, name).copy_(torch.as_tensor(v[sl].copy(), device="cuda:0"))
+    ag.clf.copy_(torch.as_tensor(chain_classifiers(m, NOPT), device="cuda:0"))
+    ag.enabled_mask = MASK
+    ag.W.copy_(torch.as_tensor(random_weights(NOPT + 1, 4, std=0.05), device="cuda:0"))
+    for _ in range(6):
+        ag.step_batch()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"ordered{rank}.npz"), W=ag.W.cpu().numpy(), x=ag.state.x.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_processes_with_the_order_pinned_sum_equal_the_oracle(tmp_path):
+    """SkillChainingAgent(group=WORLD, ordered_sum=True) in three rank processes on cuda:0 (gloo through the host): identical
+    weights on all ranks, equal bit for bit to the oracle's three shards summed in rank order."""
+    import torch.multiprocessing as mp
+    R, n = 3, 300
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_rank_main_ordered, args=(R, port, str(tmp_path)), nprocs=R, join=True)
+    res = [np.load(tmp_path / f"ordered{r}.npz") for r in range(R)]
+    assert all(np.array_equal(res[0]["W"], res[r]["W"]) for r in range(R))
+    from util import HP, SCALE
+    import skill_chaining_with_graphs_amd as scg
+    m = scg.load_map("pinball_simple")
+    x, y, vx, vy = random_states(m, R * n, 77, vmax=1.0)
+    clf = chain_classifiers(m, NOPT)
+    W_o = random_weights(NOPT + 1, 4, std=0.05)
+    orcs, sts = [], []
+    for r in range(R):
+        orcs.append(sc_oracle.Oracle(m, SCALE, n_envs=n, n_options=NOPT, seed=SEED, env_id_base=r * n, enabled_mask=MASK, n_threads=4, **HP))
+        st = sc_oracle.new_state(n, m)
+        sl = slice(r * n, (r + 1) * n)
+        st["x"][:], st["y"][:], st["vx"][:], st["vy"][:] = x[sl], y[sl], vx[sl], vy[sl]
+        sts.append(st)
+    for t in range(6):
+        out = [orcs[r].step(sts[r], W_o, clf, t) for r in range(R)]
+        g_sum, n_sum = out[0][0].copy(), out[0][1].copy()
+        for r in range(1, R):
+            g_sum = (g_sum + out[r][0]).astype(np.float32)
+            n_sum = n_sum + out[r][1]
+        orcs[0].apply(W_o, g_sum, n_sum)
+    assert np.array_equal(res[0]["W"], W_o)
+    for r in range(R):
+        assert np.array_equal(res[r]["x"], sts[r]["x"])

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import sc_oracle
+import skill_chaining_with_graphs_amd as scg
 from gpu_util import assert_state_equal, dev, make_pair, state_to_device
 from util import chain_classifiers, random_states, random_weights
 
@@ -235,6 +236,30 @@ def test_packed_gradient_operand_matches_the_split_pair():
         ctx.apply_update_packed(W_d.view(-1), gp)
         assert np.array_equal(W_d.cpu().numpy(), W_o), t
     assert n_k[1:].sum() > 0
+
+
+@pytest.mark.parametrize("n_slots", [1, 3, 8])
+def test_order_pinned_slot_sum_is_the_sequential_float_sum(n_slots):
+    """scg_apply_update_slots: G and the counts are the slots' sums IN SLOT ORDER (SPEC §5 multi-rank form), then the usual
+    update — against float32 additions in numpy in the same order and the oracle's apply; host checks included."""
+    nopt = 2
+    ctx, orc, m = make_pair("pinball_simple", 64, n_options=nopt, seed=1)
+    per = (nopt + 1) * 5 * 1296 + nopt + 1
+    rng = np.random.default_rng(50 + n_slots)
+    slots = (rng.standard_normal((n_slots, per)) * rng.choice([1e-3, 1.0, 1e3], size=(n_slots, 1))).astype(np.float32)
+    counts = rng.integers(0, 5000, size=(n_slots, nopt + 1))
+    counts[:, 1] = 0                                                  # a value function nobody updated stays untouched
+    slots[:, per - (nopt + 1):] = counts.astype(np.float32)
+    W_o = random_weights(nopt + 1, 9, std=0.05)
+    W_d = dev(W_o.copy())
+    ctx.apply_update_slots(W_d.view(-1), dev(slots))
+    g = slots[0, :per - (nopt + 1)].copy()
+    for r in range(1, n_slots):
+        g = (g + slots[r, :per - (nopt + 1)]).astype(np.float32)
+    orc.apply(W_o, g.reshape(nopt + 1, 5, 1296), counts.sum(axis=0).astype(np.int32))
+    assert np.array_equal(W_d.cpu().numpy(), W_o)
+    with pytest.raises(scg.ScgError):
+        ctx.apply_update_slots(W_d.view(-1), dev(slots)[:, :-1].contiguous())
 
 
 @pytest.mark.parametrize("n,dist", [

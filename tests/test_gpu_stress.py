@@ -96,6 +96,14 @@ def test_long_rollout_bit_exact():
     assert np.isfinite(W_o).all() and goals > 0 and timeouts > 0
 
 
+def test_eight_hundred_learning_step_batches_bit_exact():
+    """tests/long_parity.py at 800 step-batches (2048 envs, root + 3 options, alpha 0.02: the learner reaches the goal thousands of
+    times and W grows to the hundreds): a race rare enough to survive the 10-30 step rollouts would have 1.6 M env-steps to show."""
+    import long_parity
+    goals, wmax = long_parity.run(800, 2048, 3, check_every=20)
+    assert goals > 500 and np.isfinite(wmax) and wmax > 10.0
+
+
 @pytest.mark.parametrize("which", ["dense160", "hub12", "hub20"])
 def test_fused_physics_on_crowded_maps_bit_exact(which):
     """The fused step's edge-parallel physics where it is busiest: 160 edges (four candidate-mask words), and hubs of thin
