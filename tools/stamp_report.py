@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT]
 ap = argparse.ArgumentParser(); ap.add_argument("--options", type=int, default=5); ap.add_argument("--steps", type=int, default=50)
 args = ap.parse_args()
 from skill_chaining_with_graphs_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libscg_hip_stamps.so")
+_lib.LIB_PATH = os.environ.get("SCG_STAMPS_LIB") or os.path.join(os.path.dirname(_lib.LIB_PATH), "libscg_hip_stamps.so")   # SCG_STAMPS_LIB: a variant stamps build
 import numpy as np, torch
 import bench
 from skill_chaining_with_graphs_amd import SkillChainingAgent
