@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--options", type=int, default=N_OPTIONS)
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
+    ap.add_argument("--ordered-sum", action="store_true", help="with --shared-weights: one all-gather + the sum in rank order "
+                    "inside the apply launch (scg_apply_update_slots: bit-identical weights on any rank count) instead of the all-reduce")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = CPU-side rehearsal of the N>1 path on a 1-GPU box (every rank computes on cuda:0)")
     ap.add_argument("--block-envs", type=int, default=None, choices=[64, 128, 256],
@@ -275,7 +277,7 @@ def main():
     lo = rank * n_local
     group = dist.group.WORLD if (distributed and args.shared_weights) else None
     agent = SkillChainingAgent(MAP, n_local, n_opt, device=local_rank, seed=0, env_id_base=lo, group=group,
-                               block_envs=args.block_envs, **HP)
+                               block_envs=args.block_envs, ordered_sum=args.ordered_sum, **HP)
     agent.clf.copy_(torch.as_tensor(chain_discs(agent.map, n_opt)))
     for k in range(1, n_opt + 1):
         agent.enable_option(k)
@@ -348,7 +350,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n_local} envs/GPU x {world} GPU, map {MAP}, Fourier order 5 (1296 terms), "
                                    f"root + {n_opt} chained options (synthetic nested-disc initiation sets), "
-                                   f"{'shared option-Q weights, RCCL all-reduce of dW' if group is not None else 'independent env shards, no collective'}",
+                                   f"{('shared option-Q weights, ' + ('all-gather of dW + sum in rank order' if args.ordered_sum else 'RCCL all-reduce of dW')) if group is not None else 'independent env shards, no collective'}",
                        "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP,
                        "block_envs": agent.ctx.block_envs,
                        "untimed_ramp_steps": args.ramp,      # step-batches run BEFORE the warm-up: clocks up, env order prepared;
@@ -357,8 +359,9 @@ def main():
             "ranks": {"world_size_seen": world_seen, "ms_per_step_min": min(dt_ranks) / args.steps * 1e3,
                       "ms_per_step_max": max(dt_ranks) / args.steps * 1e3,
                       "allreduce": (None if ar is None else dict(ar, bytes=int(agent.ctx.grad_packed().numel()) * 4,
-                                    note="event pair on the step's stream round the packed all-reduce of rank 0: the collective "
-                                         "as the step sees it (fully exposed: the next launch needs its result)"))},
+                                    note="event pair on the step's stream round rank 0's collective on the packed operand (the all-reduce, or with "
+                                         "--ordered-sum the all-gather): the collective as the step sees it (fully exposed: the next "
+                                         "launch needs its result)"))},
             "roofline": {"bound": "hbm", "kernel": "td_kernel<MODE_FUSED>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms, "launches": int(k_n.value),
