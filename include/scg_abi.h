@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 3
+#define SCG_ABI_VERSION 3          /* 2: SCG_ASYNC_STEP_HANDOFF, announced-trigger pointer check, 256-env blocks; 3: scg_apply_update_slots */
 #define SCG_NUM_ACTIONS 5
 #define SCG_FOURIER_ORDER 5
 #define SCG_NUM_FEATURES 1296      /* (order+1)^4 */
