@@ -43,6 +43,7 @@ class ScgContext:
             raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")
         if not (0 <= n_options <= MAX_OPTIONS):
             raise ScgError(f"n_options must be in [0, {MAX_OPTIONS}]")
+        self.baseline_cache = None                           # SPEC §5.4 (enable_cached_baseline)
         self.lib = _lib.load(block_envs)                     # None: the 256-env build; 64 / 128: the small-batch builds (SPEC §5 geometry)
         self.block_envs = int(self.lib.scg_block_envs())
         self.n_envs, self.n_options, self.n_vf = int(n_envs), int(n_options), int(n_options) + 1
@@ -98,6 +99,33 @@ class ScgContext:
                    c.max_episode_steps, c.max_option_steps)
 
     # ------------------------------------------------------------------ fused step-batch
+    def _step_flags(self, learn: bool, apply: bool) -> int:
+        f = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
+        if learn and self.baseline_cache is not None:
+            f |= _lib.STEP_CACHED_QSA
+        return f
+
+    def enable_cached_baseline(self, on: bool = True, restore: Optional[torch.Tensor] = None) -> None:
+        """SPEC §5.4: learning steps take Q(s, a) of the root's items and of a block's prefix option's own items from what the
+        PREVIOUS step evaluated (one update stale) instead of evaluating it again under the current weights — the step's phase P
+        loses its largest stage. The first learning step after this call, after invalidate_order() or after an
+        acting-only step evaluates exactly and fills the cache. In this mode invalidate_order() must follow ANY outside write
+        of the env state or qcache. `restore`: a saved cache ([n_envs, 8] floats) that is valid for the states to come."""
+        if not on:
+            self.baseline_cache = None
+            self._call("scg_set_baseline_cache", C.c_void_p(0), C.c_int32(0))
+            return
+        buf = torch.zeros((self.n_envs, 8), dtype=torch.float32, device=self.device)
+        if restore is not None:
+            buf.copy_(restore.to(self.device))
+        self.baseline_cache = buf                         # caller-owned as far as the library is concerned: held here
+        self._call("scg_set_baseline_cache", _ptr(buf), C.c_int32(1 if restore is not None else 0))
+
+    def baseline_cache_valid(self) -> bool:
+        v = C.c_int32(0)
+        self._call("scg_baseline_cache_valid", C.byref(v))
+        return bool(v.value)
+
     def step(self, st: "EnvState", W: torch.Tensor, clf: torch.Tensor, enabled_mask: int, t: int,
              learn: bool = True, apply: bool = True) -> None:
         # the validated, pre-marshalled pointer arguments of the last call are reused while the same tensors come back
@@ -109,7 +137,7 @@ class ScgContext:
                st.action.data_ptr(), st.reward.data_ptr(), st.done.data_ptr(), W.data_ptr(), clf.data_ptr())
         cached = getattr(self, "_step_args", None)
         if cached is not None and cached[0] == key:
-            flags = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
+            flags = self._step_flags(learn, apply)
             _lib.check(self._step_fn(self._ctx, *cached[1], C.c_uint32(enabled_mask), C.c_uint64(t), C.c_uint32(flags),
                                      self._stream()), self._ctx, "scg_step")
             return
@@ -123,7 +151,7 @@ class ScgContext:
         self._chk(st.done, u8, N, "done")
         self._chk(W, f32, self.n_vf * NUM_ACTIONS * NUM_FEATURES, "W")
         self._chk(clf, f32, self.n_vf * CLF_STRIDE, "clf")
-        flags = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
+        flags = self._step_flags(learn, apply)
         if st is not getattr(self, "_last_state", None):      # another state object (its memory may be recycled)
             self.invalidate_order()
             self._last_state = st

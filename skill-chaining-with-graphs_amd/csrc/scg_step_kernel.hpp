@@ -483,6 +483,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
             float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
             float qc[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float4 q0a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float q0b = 0.0f;
             if (valid) {
                 // entry state first: the helper waves can start on it (Z_d^1, the block's option, W staging) while the action is drawn
                 // (all of the env's gathers are issued together: one memory round trip behind the perm lookup)
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
                 for (int aa = 0; aa < NACT; ++aa) qc[aa] = A.qcache[(size_t)aa * N + e];
                 ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];
+                if (A.learn & 2u) { q0a = A.q0cache[2 * (size_t)e]; q0b = A.q0cache[2 * (size_t)e + 1].x; }     // SPEC §5.4: the root's Q(s, .) of last step
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
                 s_ot[i] = (uint8_t)o;
@@ -513,6 +516,14 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 a = explore ? a_rand : a_greedy;
                 s_a[i] = (uint8_t)a;
+                if (A.learn & 2u) {
+                    // SPEC §5.4: Q(s, a) as the previous step evaluated it — the running value function's from qcache, the root's
+                    // from the baseline cache when the env runs an option
+                    const float qr = a == 0 ? qc[0] : a == 1 ? qc[1] : a == 2 ? qc[2] : a == 3 ? qc[3] : qc[4];
+                    const float q0 = a == 0 ? q0a.x : a == 1 ? q0a.y : a == 2 ? q0a.z : a == 3 ? q0a.w : q0b;
+                    s_maxq[i] = (o >= 1 && o < A.n_vf) ? q0 : qr;          // (s_maxq is free until E; moved to s_qsa by list position behind phase P)
+                    s_maxq[BLOCK_ENVS + i] = qr;
+                }
             } else {
                 s_a[i] = 0;
             }
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 // to the caller's arrays in env order
                 {
                     const int osn = keep ? osteps + 1 : 0, epn = dn ? 0 : eps1;
-                    float4 *orec = A.outrec + (size_t)(e0 + i) * 4;
+                    float4 *orec = A.outrec + (size_t)(e0 + i) * OREC;
                     orec[0] = make_float4(nx, ny, nvx, nvy);
                     orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
                                           __int_as_float(osn), __int_as_float(epn));
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
         SCG_HSTAMP(14);
-        run_u1_dyn();
+        if (!(A.learn & 2u)) run_u1_dyn();                        // (SPEC §5.4: with the baseline cache the merged pass needs no U1)
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
@@ -758,6 +769,16 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
+    // SPEC §5.4: the cached Q(s, a) of the merged pass's items, from env position (phase P) to update-list position (U2 reads them
+    // there, where U1 would have put them); s_maxq is rewritten by E only behind two more barriers
+    if (MODE == MODE_FUSED && (A.learn & 2u)) {
+        const int li = tid - (THREADS - BLOCK_ENVS);
+        if (li >= 0 && li < nb) {
+            const int il = s_ulist[li];
+            s_qsa[li] = s_maxq[il];
+            s_qsa[BLOCK_ENVS + li] = s_maxq[BLOCK_ENVS + il];
+        }
+    }
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s_next (and of s where no helper did it)
     for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {     // thread -> (state sg, env i, variable d): four consecutive lanes write one env's 32 bytes
         const int i = (u >> 2) & (BLOCK_ENVS - 1), d = u & 3, sg = u / (4 * BLOCK_ENVS);      // (one lane per env and variable 64 bytes apart was a 32-way bank conflict)
@@ -828,7 +849,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 s_rk[ft] = rk; s_ck[ft] = cont;
             }
-            evA = (on == kA) || (up && cont > 0.0f);
+            evA = (on == kA) || (up && cont > 0.0f) || (MODE == MODE_FUSED && (A.learn & 4u) && kA == 0);      // (SPEC §5.4: the cache takes Q_0 of EVERY s_next)
             if (kBp >= 1) evB = (on == kBp) || (ot == kBp && A.learn && s_co[ft] > 0.0f);
             at = s_a[ft];
             s_ev[ft] = (uint8_t)((evA ? 1 : 0) | (evB ? 2 : 0));
@@ -1006,7 +1027,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 asm volatile("" : "+v"(n16o), "+v"(go));     //  would otherwise be hoisted out of the unit loop and spilled)
                 contract_g(A.W + (size_t)kg * NACT * NF, B, qo, n16o, go, ab_lane);
                 if (out_lane && have) {
-                    float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                    float4 *orec = A.outrec + (size_t)(e0 + il) * OREC;
                     orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
                     orec[3].x = qo[4];
                 }
@@ -1020,15 +1041,19 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 contract(v * W_FLOATS, B, qo, n16, g, w4, w8, ab_lane);
                 if (out_lane && have && ((s_ev[il] >> v) & 1)) {
                     const int kv = v ? kBp : kA;
-                    if (s_on[il] == kv) {
-                        if (MODE == MODE_FUSED) {         // into the env's result line; commit_row writes qcache
-                            float4 *orec = A.outrec + (size_t)(e0 + il) * 4;
+                    if (MODE == MODE_FUSED) {             // into the env's result line; commit_row writes qcache (and, SPEC §5.4, the baseline cache)
+                        float4 *orec = A.outrec + (size_t)(e0 + il) * OREC;
+                        if (s_on[il] == kv) {
                             orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
                             orec[3].x = qo[4];
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + e0 + il], qo[a]);
                         }
+                        if ((A.learn & 4u) && kv == 0) {  // Q_0(s_next, .) of EVERY env
+                            orec[4] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                            orec[5].x = qo[4];
+                        }
+                    } else if (s_on[il] == kv) {
+#pragma unroll
+                        for (int a = 0; a < NACT; ++a) gstore(&A.qcache[(size_t)a * N + e0 + il], qo[a]);
                     }
                     float mx = qo[0];
 #pragma unroll
