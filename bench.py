@@ -403,7 +403,11 @@ def main():
         if world == 1 and not args.no_extras and not (args.diag_no_td or args.diag_fresh_sort or args.no_learn):
             del agent                                   # free the headline agent's buffers first
             torch.cuda.empty_cache()
-            out["extras"] = extra_measurements(args.steps, args.warmup)
+            try:                                        # the extras never cost the headline its line
+                out["extras"] = extra_measurements(args.steps, args.warmup)
+            except Exception as e:                      # noqa: BLE001 — reported in the line, loudly, not swallowed
+                out["extras"] = {"error": f"{type(e).__name__}: {e}"}
+                print(f"bench.py: the extra measurements failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:
