@@ -1326,6 +1326,15 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     if ((flags & SCG_STEP_CACHED_QSA) && !c->q0cache)
         return fail(c, SCG_ERR_STATE, "scg_step: SCG_STEP_CACHED_QSA without a baseline cache (scg_set_baseline_cache)");
     if (cache_step) {
+        // the cache is the caller's buffer, read and written by this step: refuse to launch if it is no longer device memory
+        // (freed since scg_set_baseline_cache) instead of faulting the GPU; the mode is then off until it is announced again
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, c->q0cache) != hipSuccess || at.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            c->q0cache = nullptr; c->q0_valid = false;
+            return fail(c, SCG_ERR_STATE, "scg_step: the buffer announced with scg_set_baseline_cache is no longer device memory "
+                                          "(freed before scg_set_baseline_cache(NULL)?); the cached baseline has been turned off");
+        }
         A.q0cache = c->q0cache;
         A.learn |= 4u | ((c->q0_valid && (c->q0_any_ids || c->q0_ids == option_id)) ? 2u : 0u);
     }

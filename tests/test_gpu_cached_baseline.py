@@ -142,3 +142,23 @@ def test_the_flag_without_a_cache_is_refused():
     rc = ag.ctx.lib.scg_step(ag.ctx._ctx, *ptrs, C.c_uint32(0), C.c_uint64(1), C.c_uint32(_lib.STEP_LEARN | _lib.STEP_APPLY | _lib.STEP_CACHED_QSA), None)
     assert rc == -4 and b"scg_set_baseline_cache" in ag.ctx.lib.scg_last_error(ag.ctx._ctx)
     ag.step_batch()                                            # the context is still usable
+
+
+def test_a_freed_cache_buffer_is_refused_not_dereferenced():
+    """The baseline cache is the caller's buffer, read and written by every flagged step (the Python context holds it; a C-ABI
+    caller could free it): a step whose cache is no longer device memory is refused (SCG_ERR_STATE) and the mode turned off."""
+    import gc
+    from skill_chaining_with_graphs_amd import ScgError, SkillChainingAgent
+    from util import HP
+    ag = SkillChainingAgent("pinball_simple", 512, 0, seed=1, cached_baseline=True, **HP)
+    ag.step_batch(); ag.step_batch()
+    assert ag.ctx.baseline_cache_valid()
+    big = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda:0")        # its own segment: goes back to the driver on empty_cache
+    ag.ctx._call("scg_set_baseline_cache", C.c_void_p(big.data_ptr()), C.c_int32(0))
+    del big
+    gc.collect(); torch.cuda.empty_cache()
+    with pytest.raises(ScgError, match="no longer device memory"):
+        ag.step_batch()
+    ag.ctx.baseline_cache = None                               # what the library did on its side: the mode is off
+    ag.step_batch()
+    assert ag.ctx.async_status(synchronize=True) == 0 and not ag.ctx.baseline_cache_valid()
