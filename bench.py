@@ -181,22 +181,6 @@ def extra_measurements(steps, warmup):
         ex[key] = {"value": n1 / dt, "unit": "env-steps/s", "us_per_step": dt * 1e6, "block_envs": ag.ctx.block_envs,
                    "workgroups": -(-n1 // ag.ctx.block_envs), "envs_in_an_option_at_end": int((ag.state.option_id > 0).sum())}
         del ag
-    # the headline workload with SPEC §5.4's cached baseline (opt-in: another update rule — Q(s, a) one update stale — not the headline's)
-    ag = SkillChainingAgent(MAP, ENVS_PER_GPU, N_OPTIONS, seed=0, cached_baseline=True, **HP)
-    ag.clf.copy_(torch.as_tensor(chain_discs(ag.map, N_OPTIONS)))
-    for k in range(1, N_OPTIONS + 1):
-        ag.enable_option(k)
-    ag.init_weights(std=1e-3, seed=0)
-    ag.domain.reset_random(seed=1000, v_max=1.0)
-    for _ in range(200):
-        ag.step_batch()
-    dt = _time_steps(ag, max(steps, 200), warmup)
-    ex["cached_baseline_65536_envs"] = {"value": ENVS_PER_GPU / dt, "unit": "env-steps/s", "us_per_step": dt * 1e6,
-                                         "update_rule": "SPEC 5.4: Q(s, a) of the root's items and of a block's prefix option's own items from the previous "
-                                                        "step's evaluations (one update stale); everything else as the headline",
-                                         "envs_in_an_option_at_end": int((ag.state.option_id > 0).sum()),
-                                         "weights_finite": bool(torch.isfinite(ag.W).all())}
-    del ag
     # configs[2] on discovered options
     hp = dict(HP, alpha=0.02, r_option_success=10000.0)       # a learning rate at which the root reaches the goal within the untimed
     ag = SkillChainingAgent(MAP, ENVS_PER_GPU, N_OPTIONS, seed=0, **hp)     # warm-up; completion reward of the goal's scale (DESIGN: chain evidence)
@@ -234,8 +218,6 @@ def main():
                     "inside the apply launch (scg_apply_update_slots: bit-identical weights on any rank count) instead of the all-reduce")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = CPU-side rehearsal of the N>1 path on a 1-GPU box (every rank computes on cuda:0)")
-    ap.add_argument("--cached-baseline", action="store_true", help="SPEC §5.4 (opt-in, NOT the headline): Q(s, a) from the previous step's "
-                    "evaluations, one update stale — no U1 in the merged pass")
     ap.add_argument("--block-envs", type=int, default=None, choices=[64, 128, 256],
                     help="SPEC §5 block size = library build (default 256, the throughput build; 64 / 128: the small-batch builds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -295,7 +277,7 @@ def main():
     lo = rank * n_local
     group = dist.group.WORLD if (distributed and args.shared_weights) else None
     agent = SkillChainingAgent(MAP, n_local, n_opt, device=local_rank, seed=0, env_id_base=lo, group=group,
-                               block_envs=args.block_envs, ordered_sum=args.ordered_sum, cached_baseline=args.cached_baseline, **HP)
+                               block_envs=args.block_envs, ordered_sum=args.ordered_sum, **HP)
     agent.clf.copy_(torch.as_tensor(chain_discs(agent.map, n_opt)))
     for k in range(1, n_opt + 1):
         agent.enable_option(k)
@@ -370,7 +352,7 @@ def main():
                                    f"root + {n_opt} chained options (synthetic nested-disc initiation sets), "
                                    f"{('shared option-Q weights, ' + ('all-gather of dW + sum in rank order' if args.ordered_sum else 'RCCL all-reduce of dW')) if group is not None else 'independent env shards, no collective'}",
                        "envs_per_gpu": n_local, "n_options": n_opt, "map": MAP, "hparams": HP,
-                       "block_envs": agent.ctx.block_envs, "cached_baseline": bool(args.cached_baseline),
+                       "block_envs": agent.ctx.block_envs,
                        "untimed_ramp_steps": args.ramp,      # step-batches run BEFORE the warm-up: clocks up, env order prepared;
                                                               # `value` is therefore a steady-state figure
                        "backend": ("none" if not distributed else args.backend)},

@@ -26,8 +26,10 @@
 extern "C" {
 #endif
 
-#define SCG_ABI_VERSION 4          /* 2: SCG_ASYNC_STEP_HANDOFF, announced-trigger pointer check, 256-env blocks; 3: scg_apply_update_slots;
-                                      4: SCG_STEP_CACHED_QSA, scg_set_baseline_cache, scg_baseline_cache_valid */
+#define SCG_ABI_VERSION 5          /* 2: SCG_ASYNC_STEP_HANDOFF, announced-trigger pointer check, 256-env blocks; 3: scg_apply_update_slots;
+                                      4: a second update rule (SCG_STEP_CACHED_QSA + a baseline cache); 5: that rule and its two entry
+                                      points are gone again (its definition depended on the launch geometry and it was never the
+                                      default), SPEC §4.2's exit rule (an option that ends bootstraps from the root) */
 #define SCG_NUM_ACTIONS 5
 #define SCG_FOURIER_ORDER 5
 #define SCG_NUM_FEATURES 1296      /* (order+1)^4 */
@@ -60,14 +62,6 @@ typedef struct {
 /* flags for scg_step */
 #define SCG_STEP_LEARN 1u        /* accumulate the TD gradient (otherwise act + physics + qcache only) */
 #define SCG_STEP_APPLY 2u        /* apply it to W in the same call (single-rank path) */
-#define SCG_STEP_CACHED_QSA 4u   /* SPEC §5.4 (ABI 4), with LEARN: take Q_v(s, a) of the root's items and of a running option's own items
-                                  * from what the PREVIOUS step evaluated (one update stale: the root's values from the baseline cache
-                                  * announced with scg_set_baseline_cache, the option's from `qcache`) instead of evaluating it again under
-                                  * the current weights — the largest single stage of the step's phase P goes away. The cache is valid
-                                  * after a learning step with this flag; the first such step (and the first after scg_invalidate_order,
-                                  * an acting-only step or a learning step without the flag) evaluates exactly and fills it. In this mode
-                                  * scg_invalidate_order must follow ANY outside write of the env state or of `qcache`. Off-policy items of
-                                  * a gestating option are always evaluated under the current weights. */
 
 int scg_abi_version(void);
 int scg_block_envs(void);            /* SPEC §5 block size this library was built with (one 16-wavefront workgroup per block): 256 for libscg_hip.so;
@@ -155,13 +149,6 @@ int scg_set_option_parents(scg_ctx *ctx, const int32_t *parents);
  * the stale order (slower, and not the canonical rounding). A different `option_id` pointer is noticed
  * automatically. */
 int scg_invalidate_order(scg_ctx *ctx);
-
-/* SPEC §5.4 baseline cache for SCG_STEP_CACHED_QSA: a caller-owned device buffer of n_envs * 8 floats (env e: Q_0(s_e, .) in floats
- * [8 e, 8 e + 5)), written by every learning step that carries the flag; NULL turns the mode off. `valid` != 0 declares the
- * buffer's content to be what the last such step left (a restored checkpoint). scg_baseline_cache_valid reports whether the next
- * flagged step will use the cache (1) or evaluate exactly and fill it (0). */
-int scg_set_baseline_cache(scg_ctx *ctx, float *q0cache, int32_t valid);
-int scg_baseline_cache_valid(scg_ctx *ctx, int32_t *valid);
 
 /* ---- outer-loop support (SPEC §7): device-resident trajectory ring + per-step events,
  * so that the host skill-discovery loop never has to read env state every step.

@@ -234,29 +234,27 @@ typedef struct {
 typedef struct {
     int env;      /* block-local env index */
     int upd, tgt, cache;
-    int cache0;   /* SPEC §5.4: Q(s_next, .) also goes to q0cache (root pass, every env) */
-    int cached;   /* SPEC §5.4: Q(s, a) of this update item comes from the previous step's cache (qsa_c) */
-    float qsa_c;
     float r, cont;
+    int boot;     /* SPEC §4.2 exit rule: the target is r + gamma * boot_v (the root's max_a Q_0(s_next, a)) */
+    float boot_v, boot_g;
 } td_item;
 
 static void block_vf_pass(const float *Wk, int n_items, const td_item *items, const env_rec *rec,
-                          const st_tab *tab_s, const st_tab *tab_n, float *qcache, float *q0cache, int qstride,
-                          const int *env_of, float *Pout, int *n_upd) {
+                          const st_tab *tab_s, const st_tab *tab_n, float *qcache, int qstride,
+                          const int *env_of, float *Pout, int *n_upd, float *maxq_env) {
     /* evaluations (order-free: each item's Q values depend on nothing else) */
     float *maxq = (float *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(float));
     for (int i = 0; i < n_items; ++i) {
         const td_item *it = &items[i];
-        if (it->tgt || it->cache || it->cache0) {
+        if (it->tgt || it->cache) {
             float qn[NACT];
             for (int a = 0; a < NACT; ++a) qn[a] = q_value(Wk + a * NF, a, &tab_n[it->env]);
             if (it->cache)
                 for (int a = 0; a < NACT; ++a) qcache[(size_t)a * qstride + env_of[it->env]] = qn[a];
-            if (it->cache0)
-                for (int a = 0; a < NACT; ++a) q0cache[(size_t)a * qstride + env_of[it->env]] = qn[a];
             float m = qn[0];
             for (int a = 1; a < NACT; ++a) m = fmaxf(m, qn[a]);
             maxq[i] = m;
+            if (maxq_env) maxq_env[it->env] = m;
         }
     }
     /* SPEC §5 accumulation: per action, the run of update items in block order, in groups of four (the last
@@ -271,8 +269,8 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
         for (int i = 0; i < n_items; ++i) {
             const td_item *it = &items[i];
             if (!it->upd || rec[it->env].a != act) continue;
-            float qsa = it->cached ? it->qsa_c : q_value(Wk + act * NF, act, &tab_s[it->env]);
-            float target = it->tgt ? fmaf(it->cont, maxq[i], it->r) : it->r;
+            float qsa = q_value(Wk + act * NF, act, &tab_s[it->env]);
+            float target = it->boot ? fmaf(it->boot_g, it->boot_v, it->r) : (it->tgt ? fmaf(it->cont, maxq[i], it->r) : it->r);
             dl[m] = target - qsa;
             run[m++] = it->env;
         }
@@ -334,13 +332,13 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
             for (int d = 0; d < 4; ++d) { rec[i].s[d] = s4[d][e]; rec[i].sn[d] = sn4[d][e]; }
             rec[i].a = action[e];
             items[i].env = i; items[i].upd = 1; items[i].tgt = cont[e] > 0.0f; items[i].cache = 0;
-            items[i].cache0 = 0; items[i].cached = 0; items[i].qsa_c = 0.0f;
+            items[i].boot = 0; items[i].boot_v = 0.0f; items[i].boot_g = 0.0f;
             items[i].r = r[e]; items[i].cont = cont[e];
             state_tables(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], tab_s[i].AB, tab_s[i].CD);
             if (items[i].tgt)
                 state_tables(rec[i].sn[0], rec[i].sn[1], rec[i].sn[2], rec[i].sn[3], tab_n[i].AB, tab_n[i].CD);
         }
-        block_vf_pass(Wk, nb, items, rec, tab_s, tab_n, dummy_q, NULL, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b]);
+        block_vf_pass(Wk, nb, items, rec, tab_s, tab_n, dummy_q, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b], NULL);
         free(rec); free(items); free(tab_s); free(tab_n);
     }
     int total = 0;
@@ -433,7 +431,8 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         float r0[SCO_BLOCK_ENVS], c0[SCO_BLOCK_ENVS], ro[SCO_BLOCK_ENVS], co[SCO_BLOCK_ENVS];
         unsigned gs[SCO_BLOCK_ENVS];
         float rg[SCO_BLOCK_ENVS][8], cg[SCO_BLOCK_ENVS][8];
-        float qa_run[SCO_BLOCK_ENVS], qa_root[SCO_BLOCK_ENVS];
+        float rootmax[SCO_BLOCK_ENVS];           /* max_a Q_0(s_next, a) of every env whose episode goes on (root pass) */
+        unsigned xo[SCO_BLOCK_ENVS], xg[SCO_BLOCK_ENVS];   /* exit-rule flags: bit 0 own option ended (episode goes on), bit 1 by success; xg: per gestating k, 2 bits each */
         st_tab *tab_s = (st_tab *)malloc(sizeof(st_tab) * nb);
         st_tab *tab_n = (st_tab *)malloc(sizeof(st_tab) * nb);
         td_item *items = (td_item *)malloc(sizeof(td_item) * nb);
@@ -456,10 +455,6 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 if (q > best) { best = q; a_greedy = a; }
             }
             int a = explore ? a_rand : a_greedy;
-            /* SPEC §5.4: what the previous step cached for (s, a): the running value function's Q from qcache, the root's from
-             * q0cache when the env runs an option (read before this step overwrites either) */
-            qa_run[i] = qcache[(size_t)a * N + e];
-            qa_root[i] = (option_id[e] >= 1 && option_id[e] < n_vf && p->q0cache) ? p->q0cache[(size_t)a * N + e] : qa_run[i];
             float sx = x[e], sy = y[e], svx = vx[e], svy = vy[e];
             rec[i].s[0] = sx; rec[i].s[1] = sy; rec[i].s[2] = svx; rec[i].s[3] = svy;
             rec[i].a = a;
@@ -476,16 +471,17 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             rec[i].sn[0] = nx; rec[i].sn[1] = ny; rec[i].sn[2] = nvx; rec[i].sn[3] = nvy;
             int o = option_id[e];
             int keep = 0;
-            ro[i] = 0.0f; co[i] = 0.0f;
+            ro[i] = 0.0f; co[i] = 0.0f; xo[i] = 0; xg[i] = 0; rootmax[i] = 0.0f;
             if (o >= 1) {
                 int par = p->parents[o & 7];
                 int succ = (par == 0) ? goal : in_set(p, clf, par, sx, sy);
                 int fail = !succ && !in_set(p, clf, o, sx, sy);
                 int otime = opt_steps[e] + 1 >= p->max_option_steps;
                 int term = (dn != 0) || succ || fail || otime;
-                ro[i] = rew + (succ ? p->r_option_success : 0.0f);
+                ro[i] = (p->exit_rule == 3 ? 0.0f : rew) + (succ ? p->r_option_success : 0.0f);
                 co[i] = term ? 0.0f : p->gamma;
                 keep = !term;
+                if (term && dn == 0) xo[i] = 1u | (succ ? 2u : 0u);
             }
             int on = 0;
             if (keep) on = o;
@@ -507,8 +503,9 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 int succ = (par == 0) ? goal : in_set(p, clf, par, sx, sy);
                 int fail = !succ && !in_set(p, clf, k, sx, sy);
                 gs[i] |= 1u << k;
-                rg[i][k] = rew + (succ ? p->r_option_success : 0.0f);
+                rg[i][k] = (p->exit_rule == 3 ? 0.0f : rew) + (succ ? p->r_option_success : 0.0f);
                 cg[i][k] = (dn != 0 || succ || fail) ? 0.0f : p->gamma;
+                if (dn == 0 && (succ || fail)) xg[i] |= (1u | (succ ? 2u : 0u)) << (2 * k);
                 if (succ && p->gest_succ) {
 #pragma omp atomic
                     p->gest_succ[k] += 1;
@@ -535,15 +532,6 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             state_tables(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], tab_s[i].AB, tab_s[i].CD);
             state_tables(nx, ny, nvx, nvy, tab_n[i].AB, tab_n[i].CD);
         }
-        /* SPEC §5.4: the block's prefix option — the option k0 >= 1 (not gestating) whose envs are exactly the first positions of the
-         * block, which is what the chunked env order produces; its own items and the root's take Q(s, a) from the caches */
-        int kB = -1;
-        if (nb > 0 && o_t[0] >= 1 && o_t[0] < n_vf && !((p->gest_mask >> o_t[0]) & 1u)) {
-            int k0 = o_t[0], mB = 0, ok = 1;
-            while (mB < nb && o_t[mB] == k0) ++mB;
-            for (int i = mB; i < nb; ++i) if (o_t[i] == k0) ok = 0;
-            if (ok) kB = k0;
-        }
         /* ---- TD passes, VF by VF */
         for (int k = 0; k < n_vf; ++k) {
             int m = 0;
@@ -552,19 +540,21 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 int gst = !own && ((gs[i] >> k) & 1u);
                 int upd = own || gst;
                 int cache = (o_n[i] == k);
-                int cache0 = (k == 0) && p->q0cache != NULL;                   /* SPEC §5.4: the root is evaluated at every s_next */
-                if (!upd && !cache && !cache0) continue;
+                if (!upd && !cache) continue;
                 float cont = (k == 0) ? c0[i] : (gst ? cg[i][k] : co[i]);
-                items[m].env = i; items[m].upd = upd; items[m].cache = cache; items[m].cache0 = cache0;
-                items[m].cached = p->use_qsa_cache && p->q0cache != NULL && (k == 0 || (k == kB && o_t[i] == k));
-                items[m].qsa_c = (k == 0) ? qa_root[i] : qa_run[i];
+                items[m].env = i; items[m].upd = upd; items[m].cache = cache;
                 items[m].tgt = upd && cont > 0.0f;
                 items[m].r = (k == 0) ? r0[i] : (gst ? rg[i][k] : ro[i]);
                 items[m].cont = cont;
+                {   /* SPEC §4.2 exit rule */
+                    const unsigned xf = (k == 0) ? 0u : (gst ? (xg[i] >> (2 * k)) & 3u : (own ? xo[i] : 0u));
+                    items[m].boot = upd && (xf & 1u) && (p->exit_rule == 2 || (p->exit_rule == 1 && !(xf & 2u)));
+                    items[m].boot_v = rootmax[i]; items[m].boot_g = p->gamma;
+                }
                 ++m;
             }
-            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, tab_s, tab_n, qcache, p->q0cache, N, env_of,
-                          P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k]);
+            block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, tab_s, tab_n, qcache, N, env_of,
+                          P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k], k == 0 ? rootmax : NULL);
         }
         free(tab_s); free(tab_n); free(items);
     }

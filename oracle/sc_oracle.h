@@ -47,11 +47,11 @@ typedef struct {
     int32_t parents[8];         /* SPEC §4.2 option graph: target option of k (0 = goal); [0] unused */
     uint32_t gest_mask;         /* SPEC §4.4: options in gestation */
     int32_t *gest_succ;         /* [n_options + 1] success counters of gestating options (NULL = off) */
-    /* SPEC §5.4 cached baseline (NULL = off): q0cache[5][n_envs] receives Q_0(s_next, .) of EVERY env of a learning step; with
-     * use_qsa_cache != 0 the step takes Q_v(s, a) of the root's items and of a running option's own items from the caches the
-     * previous step left (q0cache / qcache) instead of evaluating it under the current weights */
-    float *q0cache;
-    int32_t use_qsa_cache;
+    /* SPEC §4.2 exit rule of an option's own (and gestating, §4.4) items: what an option that ENDS without the episode ending
+     * bootstraps from. 0: nothing (continuation 0 — rounds 1-4); 1: fail / time-out bootstrap from the root's value of where
+     * the env goes next, gamma * max_a Q_0(s_next, a), success ends with r + r_option_success; 2: success bootstraps too;
+     * 3 (experiment): as 0 with a pure subgoal reward — the option's reward is r_option_success on success and 0 otherwise (no step costs) */
+    int32_t exit_rule;
 } sco_params;
 
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

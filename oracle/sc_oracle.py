@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("ring_len", C.c_int32),
         ("parents", C.c_int32 * 8),
         ("gest_mask", C.c_uint32), ("gest_succ", C.c_void_p),
-        ("q0cache", C.c_void_p), ("use_qsa_cache", C.c_int32),
+        ("exit_rule", C.c_int32),
     ]
 
 
@@ -163,28 +163,11 @@ class Oracle:
         n_k = np.ascontiguousarray(n_k, np.int32)
         self.L.sco_apply(C.byref(self.p), len(n_k), _p(W), _p(_f32(G)), _p(n_k))
 
-    def set_cached_baseline(self, on=True):
-        """SPEC §5.4: Q(s, a) of the root's items and of a running option's own items from the caches the previous learning
-        step left (one update stale) instead of an evaluation under the current weights. The first step after switching it
-        on (or after invalidate_cache()) is exact and fills the cache."""
-        self.q0cache = np.zeros((NACT, self.p.n_envs), np.float32) if on else None
-        self.p.q0cache = self.q0cache.ctypes.data if on else None
-        self.q0_valid = False
-        self.p.use_qsa_cache = 0
-
-    def invalidate_cache(self):
-        self.q0_valid = False
-
-    def step(self, st, W, clf, t, enabled_mask=None, use_cache=None):
+    def step(self, st, W, clf, t, enabled_mask=None):
         """st: dict of numpy arrays (x,y,vx,vy,option_id,opt_steps,ep_steps,qcache[5,N],action,reward,done),
-        modified in place. Returns (G[n_vf,5,1296], n_k[n_vf]); W is not modified (call apply).
-        SPEC §5.4 (set_cached_baseline): the step uses the caches when the previous call left them valid — every call is taken
-        to be a learning step; a caller that mixes in acting-only steps or outside writes says so with use_cache / invalidate_cache()."""
+        modified in place. Returns (G[n_vf,5,1296], n_k[n_vf]); W is not modified (call apply)."""
         if enabled_mask is not None:
             self.p.enabled_mask = enabled_mask
-        if getattr(self, "q0cache", None) is not None:
-            self.p.use_qsa_cache = int(self.q0_valid if use_cache is None else bool(use_cache))
-            self.q0_valid = True
         G = np.zeros((self.n_vf, NACT, NF), np.float32)
         n_k = np.zeros(self.n_vf, np.int32)
         self.L.sco_step(C.byref(self.p), _p(st["x"]), _p(st["y"]), _p(st["vx"]), _p(st["vy"]),

@@ -17,8 +17,7 @@ CLF_STRIDE = 8
 
 STEP_LEARN = 1
 STEP_APPLY = 2
-STEP_CACHED_QSA = 4        # SPEC §5.4: Q(s, a) from the previous step's evaluations (scg_set_baseline_cache)
-ABI_VERSION = int(os.environ.get("SCG_LIB_ABI", "4"))   # include/scg_abi.h SCG_ABI_VERSION (SCG_LIB_ABI: A/B runs against a historical build)
+ABI_VERSION = 5            # include/scg_abi.h SCG_ABI_VERSION
 ASYNC_FIT_TIMEOUT = 0x1
 ASYNC_STEP_HANDOFF = 0x2
 
@@ -68,8 +67,6 @@ _SIGS = {
     "scg_classifier_predict": (C.c_int, [_P, C.c_int32] + [_P] * 4 + [_P]),
     "scg_set_option_parents": (C.c_int, [_P, _P]),
     "scg_invalidate_order": (C.c_int, [_P]),
-    "scg_set_baseline_cache": (C.c_int, [_P, _P, C.c_int32]),
-    "scg_baseline_cache_valid": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "scg_set_trace_buffers": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "scg_harvest": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "scg_collect_examples": (C.c_int, [_P, C.c_uint32, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P]),

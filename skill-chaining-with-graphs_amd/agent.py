@@ -20,12 +20,10 @@ from .pinball import PinballDomain
 
 class SkillChainingAgent:
     def __init__(self, pmap, n_envs: int, n_options: int = 0, *, device: int = 0, seed: int = 0,
-                 env_id_base: int = 0, group=None, ordered_sum: bool = False, cached_baseline: bool = False, **hparams):
+                 env_id_base: int = 0, group=None, ordered_sum: bool = False, **hparams):
         self.map: PinballMap = load_map(pmap) if isinstance(pmap, str) else pmap
         self.ctx = ScgContext(n_envs, n_options, self.map, device=device, seed=seed, env_id_base=env_id_base,
                               **hparams)
-        if cached_baseline:
-            self.ctx.enable_cached_baseline()             # SPEC §5.4: Q(s, a) one update stale, no U1 in the merged pass
         dev = self.ctx.device
         self.n_envs, self.n_options, self.n_vf = n_envs, n_options, n_options + 1
         self.W = torch.zeros((self.n_vf, NUM_ACTIONS, NUM_FEATURES), dtype=torch.float32, device=dev)
@@ -273,9 +271,6 @@ class SkillChainingAgent:
                              for k, (xy, lab, cnt, _) in self._ex.items()}
             d["prev_in"] = {int(k): v[3].cpu() for k, v in self._ex.items() if v[3] is not None}
         d["gest_mask"] = int(self.gest_mask)
-        if self.ctx.baseline_cache is not None:          # SPEC §5.4: a continuation must find the cache the next step would have used
-            d["baseline_cache"] = self.ctx.baseline_cache.cpu()
-            d["baseline_cache_valid"] = bool(self.ctx.baseline_cache_valid())
         d["gest_need"] = {int(k): int(v) for k, v in self._gest_need.items()}
         if self.gest_mask:
             d["gest_succ"] = self.ctx.set_gestation(self.gest_mask).cpu()
@@ -304,9 +299,6 @@ class SkillChainingAgent:
         if self.gest_mask:
             self.ctx.set_gestation(self.gest_mask).copy_(d["gest_succ"])
         self.ctx.invalidate_order()      # option ids were written outside scg_step: the next step sorts afresh (same order)
-        if "baseline_cache" in d:
-            self.ctx._last_state = self.state      # (the context would otherwise invalidate once more when it first sees this state object)
-            self.ctx.enable_cached_baseline(restore=d["baseline_cache"] if d.get("baseline_cache_valid") else None)
 
     def save(self, path: str) -> None:
         torch.save(self.state_dict(), path)

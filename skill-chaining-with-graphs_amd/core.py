@@ -43,7 +43,6 @@ class ScgContext:
             raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")
         if not (0 <= n_options <= MAX_OPTIONS):
             raise ScgError(f"n_options must be in [0, {MAX_OPTIONS}]")
-        self.baseline_cache = None                           # SPEC §5.4 (enable_cached_baseline)
         self.lib = _lib.load(block_envs)                     # None: the 256-env build; 64 / 128: the small-batch builds (SPEC §5 geometry)
         self.block_envs = int(self.lib.scg_block_envs())
         self.n_envs, self.n_options, self.n_vf = int(n_envs), int(n_options), int(n_options) + 1
@@ -100,31 +99,7 @@ class ScgContext:
 
     # ------------------------------------------------------------------ fused step-batch
     def _step_flags(self, learn: bool, apply: bool) -> int:
-        f = (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
-        if learn and self.baseline_cache is not None:
-            f |= _lib.STEP_CACHED_QSA
-        return f
-
-    def enable_cached_baseline(self, on: bool = True, restore: Optional[torch.Tensor] = None) -> None:
-        """SPEC §5.4: learning steps take Q(s, a) of the root's items and of a block's prefix option's own items from what the
-        PREVIOUS step evaluated (one update stale) instead of evaluating it again under the current weights — the step's phase P
-        loses its largest stage. The first learning step after this call, after invalidate_order() or after an
-        acting-only step evaluates exactly and fills the cache. In this mode invalidate_order() must follow ANY outside write
-        of the env state or qcache. `restore`: a saved cache ([n_envs, 8] floats) that is valid for the states to come."""
-        if not on:
-            self.baseline_cache = None
-            self._call("scg_set_baseline_cache", C.c_void_p(0), C.c_int32(0))
-            return
-        buf = torch.zeros((self.n_envs, 8), dtype=torch.float32, device=self.device)
-        if restore is not None:
-            buf.copy_(restore.to(self.device))
-        self.baseline_cache = buf                         # caller-owned as far as the library is concerned: held here
-        self._call("scg_set_baseline_cache", _ptr(buf), C.c_int32(1 if restore is not None else 0))
-
-    def baseline_cache_valid(self) -> bool:
-        v = C.c_int32(0)
-        self._call("scg_baseline_cache_valid", C.byref(v))
-        return bool(v.value)
+        return (STEP_LEARN if learn else 0) | (STEP_APPLY if (learn and apply) else 0)
 
     def step(self, st: "EnvState", W: torch.Tensor, clf: torch.Tensor, enabled_mask: int, t: int,
              learn: bool = True, apply: bool = True) -> None:

@@ -171,10 +171,12 @@ __device__ __forceinline__ int pinball_wave_prepare(const float *edges, const ui
     const float DV = 0x1.99999ap-3f, VMAX = 2.0f;
     const float4 *E4 = reinterpret_cast<const float4 *>(edges);
     const int lane = threadIdx.x & 63;
-    if (a == 0) vx = vx + DV;
-    else if (a == 2) vx = vx - DV;
-    else if (a == 1) vy = vy + DV;
-    else if (a == 3) vy = vy - DV;
+    {   // (as selects: the if / else-if chain over two by-reference floats became a dynamically indexed private array — the
+        //  velocities went through scratch memory, three dependent round trips at the head of the physics)
+        const float vxp = vx + DV, vxm = vx - DV, vyp = vy + DV, vym = vy - DV;
+        vx = a == 0 ? vxp : (a == 2 ? vxm : vx);
+        vy = a == 1 ? vyp : (a == 3 ? vym : vy);
+    }
     vx = fminf(fmaxf(vx, -VMAX), VMAX);
     vy = fminf(fmaxf(vy, -VMAX), VMAX);
     // candidate set (SPEC §1.3, last paragraph; same bound and same refinement as pinball_step)

@@ -39,14 +39,14 @@ __device__ __forceinline__ void store_wt(float *p, f4v v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" :: "v"(p), "v"(v) : "memory");
 }
 
-constexpr int OREC = 8;        // float4 per result line: [0] state', [1] {reward, bits, counters}, [2..3] Q(s', .) of the VF acting next, [4..5] SPEC §5.4 Q_0(s', .)
+constexpr int OREC = 4;        // float4 per result line (64 bytes): [0] state', [1] {reward, bits, counters}, [2..3] Q(s', .) of the VF acting next
 
 struct StepArgs {
     // env state (FUSED: in/out; TRANS/QVAL: in)
     float *x, *y, *vx, *vy;
     int32_t *option_id, *opt_steps, *ep_steps;
     int32_t *hist_next;        // [rows of 256 envs][8] counts of the option ids this step leaves (null = off)
-    float4 *outrec;            // FUSED: [positions][OREC] per-env results in env-ORDER position (one 128-byte line, 64 + 20 bytes used:
+    float4 *outrec;            // FUSED: [positions][OREC] per-env results in env-ORDER position (one 64-byte line:
                                // state', {reward, bits, counters}, Q(s', .) of the VF acting next), committed to the
                                // caller's arrays by commit_row (coalesced) instead of 4-byte scatters from here
     float *qcache;                 // [5][n]  (QVAL: output q)
@@ -69,10 +69,8 @@ struct StepArgs {
     int32_t *cnts;                 // [nblk][n_vf]
     unsigned long long *stamps;    // diagnostic build only
     uint32_t *async_word;          // host-visible sticky status word (a hand-off poll that runs out is reported there)
-    const float4 *q0cache;         // SPEC §5.4: [n][2] Q_0(s, .) of every env as the previous step left it (read when learn & 2)
     int32_t n, n_vf, k_lo, k_hi;
-    uint32_t enabled, learn;       // learn: bit 0 = learning step; SPEC §5.4: bit 1 = Q(s, a) of the root's and the running options' own items from
-                                   // the caches (no U1 for them), bit 2 = leave Q_0(s_next, .) of every env in its result line
+    uint32_t enabled, learn;       // learn: 1 = learning step
     uint32_t gest;                 // SPEC §4.4: options in gestation (classifier known, not selectable, learning off-policy)
     int32_t *gest_succ;            // [n_vf] successes seen from inside a gestating option's initiation set (atomic counts)
     uint32_t parents;              // 3 bits per option k at [3k, 3k+3): target option of k (0 = the task goal)
@@ -175,7 +173,6 @@ struct ReduceArgs {
     int32_t *option_id_out, *opt_steps, *ep_steps;
     uint8_t *action, *done;
     float *qcache;                 // [5][n], null = the step ran no TD pass (diagnostic): leave it alone
-    float4 *q0cache;               // SPEC §5.4 baseline cache: this step's Q_0(s_next, .) from the result lines -> by env (null = off)
     int32_t sort;
     // an announced example trigger (scg_arm_collect; c_rows null = none): the commit rows leave what collect_count_kernel would
     const uint8_t *c_events, *c_prev;
@@ -343,11 +340,6 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
                 const size_t n = (size_t)R.n;
                 R.qcache[e] = rq.x; R.qcache[n + e] = rq.y; R.qcache[2 * n + e] = rq.z;
                 R.qcache[3 * n + e] = rq.w; R.qcache[4 * n + e] = q4;
-            }
-            if (R.q0cache) {                                // SPEC §5.4: the step left Q_0(s_next, .) in the result line
-                const float4 *r2 = R.outrec + (size_t)pos_old * OREC;
-                R.q0cache[2 * (size_t)e] = r2[4];
-                R.q0cache[2 * (size_t)e + 1] = make_float4(r2[5].x, 0.0f, 0.0f, 0.0f);
             }
         }
         if (R.sort) {
@@ -942,10 +934,6 @@ struct scg_ctx {
     uint32_t *d_async;             // ... its device address
     double fit_timeout_s;          // how long fit_kernel waits for a workgroup that is not running yet
     float4 *d_outrec;              // [nblk * BLOCK_ENVS][OREC] per-position step results (td_kernel -> commit_row)
-    float4 *q0cache;               // caller-owned [n_envs][2] (scg_set_baseline_cache; null = the mode is off)
-    bool q0_valid;                 // the cache holds what the last step left for exactly these env states
-    bool q0_any_ids;               // ... declared valid by the caller (restored checkpoint): whatever state arrays come next
-    const int32_t *q0_ids;         // the option_id array of the step that filled it
     int32_t *d_invperm;            // [n_envs] position of each env in d_perm
     int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
     int hist_parity;
@@ -1268,7 +1256,6 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
         R.option_id_out = st->option_id; R.opt_steps = st->opt_steps; R.ep_steps = st->ep_steps;
         R.action = st->action; R.done = st->done;
         R.qcache = st->k_hi >= 0 ? st->qcache : nullptr;
-        if (st->learn & 4u) R.q0cache = c->q0cache;
         if (c->arm_bits && c->events && c->ring_x) {
             R.c_events = c->events; R.c_prev = c->arm_prev; R.c_evlen = c->ev_len; R.c_count = c->arm_count;
             R.c_rows = c->d_collect_rows; R.c_bits = c->arm_bits; R.c_L = c->arm_L; R.c_ring_len = c->ring_len;
@@ -1321,24 +1308,6 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     A.n = c->cfg.n_envs; A.k_lo = 0; A.k_hi = c->n_vf - 1;
     A.enabled = enabled_mask; A.learn = (flags & SCG_STEP_LEARN) ? 1u : 0u; A.t = t;
     if (flags & 0x100u) A.k_hi = -1;     // diagnostic only (bench.py --diag-no-td): skip the TD passes
-    // SPEC §5.4: with the flag a learning step fills the baseline cache, and uses it when the previous step left it for these states
-    const bool cache_step = (flags & SCG_STEP_CACHED_QSA) && (flags & SCG_STEP_LEARN) && c->q0cache && A.k_hi >= 0;
-    if ((flags & SCG_STEP_CACHED_QSA) && !c->q0cache)
-        return fail(c, SCG_ERR_STATE, "scg_step: SCG_STEP_CACHED_QSA without a baseline cache (scg_set_baseline_cache)");
-    if (cache_step) {
-        // the cache is the caller's buffer, read and written by this step: refuse to launch if it is no longer device memory
-        // (freed since scg_set_baseline_cache) instead of faulting the GPU; the mode is then off until it is announced again
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, c->q0cache) != hipSuccess || at.type != hipMemoryTypeDevice) {
-            (void)hipGetLastError();
-            c->q0cache = nullptr; c->q0_valid = false;
-            return fail(c, SCG_ERR_STATE, "scg_step: the buffer announced with scg_set_baseline_cache is no longer device memory "
-                                          "(freed before scg_set_baseline_cache(NULL)?); the cached baseline has been turned off");
-        }
-        A.q0cache = c->q0cache;
-        A.learn |= 4u | ((c->q0_valid && (c->q0_any_ids || c->q0_ids == option_id)) ? 2u : 0u);
-    }
-    c->q0_valid = false; c->q0_any_ids = false;
     // env order of this step (SPEC §5): counting sort by the option ids the previous step left
     // A learning step computes the NEXT step's order inside its reduce launches; the stand-alone sort runs only
     // when that order is missing or was invalidated (first step, other array, scg_invalidate_order).
@@ -1384,31 +1353,12 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     c->hist_dirty = false;
     c->hist_parity ^= 1;
     c->order_valid = true; c->order_ids = option_id;
-    if (cache_step) { c->q0_valid = true; c->q0_ids = option_id; }
     return SCG_OK;
 }
 
 int scg_invalidate_order(scg_ctx *c) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_invalidate_order: null ctx");
     c->order_valid = false;
-    c->q0_valid = false;            // SPEC §5.4: the baseline cache belongs to the states the last step left
-    return SCG_OK;
-}
-
-int scg_set_baseline_cache(scg_ctx *c, float *q0cache, int32_t valid) {
-    if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_baseline_cache: null ctx");
-    if (q0cache && (reinterpret_cast<uintptr_t>(q0cache) & 15u))
-        return fail(c, SCG_ERR_INVALID, "scg_set_baseline_cache: the buffer must be 16-byte aligned (n_envs * 8 floats)");
-    c->q0cache = reinterpret_cast<float4 *>(q0cache);
-    c->q0_valid = q0cache && valid != 0;
-    c->q0_ids = c->order_ids;       // a restored cache goes with the state arrays the next step is given
-    c->q0_any_ids = valid != 0;
-    return SCG_OK;
-}
-
-int scg_baseline_cache_valid(scg_ctx *c, int32_t *valid) {
-    if (!c || !valid) return fail(c, SCG_ERR_INVALID, "scg_baseline_cache_valid: null argument");
-    *valid = (c->q0cache && c->q0_valid) ? 1 : 0;
     return SCG_OK;
 }
 

@@ -184,13 +184,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
 
-    if (tid < M_INTS) s_misc[tid] = (tid == M_PRESENT || tid == M_UPD) ? 1 : 0;
-    if (MODE == MODE_FUSED) {
-        for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
-        if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
-    }
-    block_lds_sync();
-
     // private tables of one 8-item column block from the builder lane's item `it` (already clamped by the caller),
     // state sg (0 = s, 1 = s_next): CDk[c34][col], ABq[col][c12] with ABsel = (Re AB | -Im AB)
     auto build_tables = [&](int it, int sg, int cp, int bcol, float *cdk, float *abq) {
@@ -395,39 +388,46 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // lane (n16, g)) = W[16 t + n16][9 g + kb], rows >= 180 zero; per tile and lane the k-blocks 0..3 and 4..7 form two
     // float4 — one ds_read_b128 feeds four MFMAs — and k-block 8 sits apart), by `nth` threads with index `ht`: one thread
     // per DESTINATION float4, a 16-byte load at a 4-byte-aligned source address, one linear ds_write_b128.
-    auto stage_w = [&](const float *Wk, int dstf, int ht, int nth) {
+    struct WStage { f4v v[3]; float tl[2]; };
+    auto stage_w_load = [&](const float *Wk, int ht, int nth, WStage &st) {
         // (all of a thread's loads are issued before its first LDS store: one memory round trip per staging, not one per
         //  loop iteration — the helper waves' W_0 took 10k cycles as three dependent load -> store rounds; nth >= 512)
         struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
-        f4v *dst4 = reinterpret_cast<f4v *>(s_W + dstf);
         constexpr int N4 = 12 * 2 * 64, N1 = 12 * 64, MAXI = 3, MAXT = 2;
-        f4v v[MAXI];
-        float tl[MAXT];
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int d = ht + i * nth;
-            v[i] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            st.v[i] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
             if (d < N4) {
                 const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
                 if (row < NACT * 36) {
                     const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
-                    v[i] = (f4v){w.x, w.y, w.z, w.w};
+                    st.v[i] = (f4v){w.x, w.y, w.z, w.w};
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {                                          // k-block 8 of every tile
             const int z = ht + i * nth;
-            tl[i] = 0.0f;
+            st.tl[i] = 0.0f;
             if (z < N1) {
                 const int ln = z & 63, row = 16 * (z >> 6) + (ln & 15);
-                if (row < NACT * 36) tl[i] = Wk[row * 36 + 9 * (ln >> 4) + 8];
+                if (row < NACT * 36) st.tl[i] = Wk[row * 36 + 9 * (ln >> 4) + 8];
             }
         }
+    };
+    auto stage_w_store = [&](int dstf, int ht, int nth, const WStage &st) {
+        f4v *dst4 = reinterpret_cast<f4v *>(s_W + dstf);
+        constexpr int N4 = 12 * 2 * 64, N1 = 12 * 64, MAXI = 3, MAXT = 2;
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) { const int d = ht + i * nth; if (d < N4) dst4[d] = v[i]; }
+        for (int i = 0; i < MAXI; ++i) { const int d = ht + i * nth; if (d < N4) dst4[d] = st.v[i]; }
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i) { const int z = ht + i * nth; if (z < N1) s_W[dstf + W_TAIL + z] = tl[i]; }
+        for (int i = 0; i < MAXT; ++i) { const int z = ht + i * nth; if (z < N1) s_W[dstf + W_TAIL + z] = st.tl[i]; }
+    };
+    auto stage_w = [&](const float *Wk, int dstf, int ht, int nth) {
+        WStage st;
+        stage_w_load(Wk, ht, nth, st);
+        stage_w_store(dstf, ht, nth, st);
     };
     // counters in LDS for hand-offs between SUBSETS of the workgroup's waves (s_barrier takes all sixteen): a producer
     // publishes with lds_arrive, a consumer polls with lds_await. Every awaited count is reached by waves that never
@@ -468,23 +468,62 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         if (prefix) { kB = k0; mB = m; }
     };
+    // the root's update list geometry from the published actions (ballots; every wave that runs U1 under phase P derives it itself)
+    auto u1_geometry = [&](uint64_t (&mk)[P_WAVES][NACT], int (&at)[P_WAVES]) {
+#pragma unroll
+        for (int h = 0; h < P_WAVES; ++h) at[h] = 64 * h + lane < nb ? (int)s_a[64 * h + lane] : -1;
+        int off = 0;
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) {
+            int rl = 0, nbq = 0;
+#pragma unroll
+            for (int h = 0; h < P_WAVES; ++h) {
+                mk[h][a] = __ballot(at[h] == a);
+                rl += __popcll(mk[h][a]);
+                const int lim = mB - 64 * h;                                      // positions below mB belong to option kB
+                const uint64_t pre = lim >= 64 ? ~0ull : (lim > 0 ? ((1ull << lim) - 1ull) : 0ull);
+                nbq += __popcll(mk[h][a] & pre);
+            }
+            run_len[a] = rl; run_off[a] = off; nBa[a] = nbq; off += rl;
+        }
+    };
     // With learning on, waves 8..15 ("helpers") have nothing to do in phase P: they stage W_0 (and W_kB), take Z_d^1 of
     // the entry states, build the root's update list and run U1 of both value functions under it.
     const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
+
+    // ------------------------------------------------------------------ kernel start
+    // Every wave issues its first global loads before anybody waits for anything (round 5): the first round trips of a launch are
+    // cold ones (4-6k cycles each), and the old start — edge table -> barrier -> perm -> state gathers on the env waves,
+    // barrier -> W_0 on the helpers — paid three of them in a row on the env waves' chain and two on the helpers'.
+    int e_pre = e0 + tid;                                   // env waves: this position's env
+    if (MODE == MODE_FUSED) {
+        if (wave < P_WAVES && tid < nb && A.perm) e_pre = A.perm[e0 + tid];
+        // helper waves: W_0 goes to its place in region W (free during phase P) BEFORE the barrier: the barrier then waits for ONE
+        // cold round trip (W_0 beside the env waves' perm and the edge table) instead of standing between two. (Keeping W_0 in
+        // registers across the barrier instead — 14 per thread, helper waves only — sent the register allocator of the whole
+        // kernel over the edge: 27 spill / reload sites in E and U2 instead of 2.)
+        if (helpers && wave >= HELPER0) stage_w(A.W, 0, tid - HELPER0 * 64, N_HELP * 64);
+    }
+    if (tid < M_INTS) s_misc[tid] = (tid == M_PRESENT || tid == M_UPD) ? 1 : 0;
+    if (MODE == MODE_FUSED) {
+        // (a form with the edge loads issued together as well — two predicated loads per thread into registers — sent the register
+        //  allocator of the WHOLE kernel over the edge: 27 spill / reload sites in E and U2 instead of 2; maps up to 128 edges are one trip)
+        for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
+        if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
+    }
+    block_lds_sync();
 
     // ------------------------------------------------------------------ phase P
     if (helpers) { if (wave < P_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_P); else if (wave >= HELPER0) __builtin_amdgcn_s_setprio(SCG_PRIO_HELP); }
     if (wave < P_WAVES) {                             // one lane per env on P_WAVES full waves
         const int i = tid;
         const bool valid = i < nb;
-        const int e = (MODE == MODE_FUSED && A.perm && valid) ? A.perm[e0 + i] : e0 + i;
+        const int e = e_pre;
         if (MODE == MODE_FUSED) {
             uint32_t u[4] = {0u, 0u, 0u, 0u};
             int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
             float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
             float qc[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            float4 q0a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float q0b = 0.0f;
             if (valid) {
                 // entry state first: the helper waves can start on it (Z_d^1, the block's option, W staging) while the action is drawn
                 // (all of the env's gathers are issued together: one memory round trip behind the perm lookup)
@@ -492,7 +531,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
                 for (int aa = 0; aa < NACT; ++aa) qc[aa] = A.qcache[(size_t)aa * N + e];
                 ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];
-                if (A.learn & 2u) { q0a = A.q0cache[2 * (size_t)e]; q0b = A.q0cache[2 * (size_t)e + 1].x; }     // SPEC §5.4: the root's Q(s, .) of last step
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
                 s_ot[i] = (uint8_t)o;
@@ -516,14 +554,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 a = explore ? a_rand : a_greedy;
                 s_a[i] = (uint8_t)a;
-                if (A.learn & 2u) {
-                    // SPEC §5.4: Q(s, a) as the previous step evaluated it — the running value function's from qcache, the root's
-                    // from the baseline cache when the env runs an option
-                    const float qr = a == 0 ? qc[0] : a == 1 ? qc[1] : a == 2 ? qc[2] : a == 3 ? qc[3] : qc[4];
-                    const float q0 = a == 0 ? q0a.x : a == 1 ? q0a.y : a == 2 ? q0a.z : a == 3 ? q0a.w : q0b;
-                    s_maxq[i] = (o >= 1 && o < A.n_vf) ? q0 : qr;          // (s_maxq is free until E; moved to s_qsa by list position behind phase P)
-                    s_maxq[BLOCK_ENVS + i] = qr;
-                }
             } else {
                 s_a[i] = 0;
             }
@@ -535,6 +565,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             // the groups of ALL env waves are then dealt to waves 0..P_POOL-1
             bool par;
             float *xs_mine = s_s + 4 * BLOCK_ENVS + wave * 64;
+#ifdef SCG_DIAG_NO_PHYSICS         // (diagnostic, WRONG results: prices a step kernel WITHOUT phase P's physics at its head — VERDICT r4 item 1c)
+            goal = false; par = false;
+            const float rew = a == 4 ? -1.0f : -5.0f;
+#else
             const int groups = pinball_wave_prepare_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal, par,
                                                         s_pitems + wave * PITEMS, xs_mine, BLOCK_ENVS);
             if (lane == 0) s_misc[M_GROUPS + wave] = groups;
@@ -557,6 +591,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 lds_await(&s_misc[M_C_POOL], P_POOL);
             }
             const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
+#endif
             SCG_STAMP(2);                                         // P: physics, the pooled pair groups + hand-offs
             int hkey = -1;
             if (valid) {
@@ -678,6 +713,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             s_a[i] = 0; s_ot[i] = 255; s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
         }
     } else if (MODE == MODE_FUSED && wave < P_POOL) {   // no envs of its own: takes its share of the physics' pair groups
+#ifndef SCG_DIAG_NO_PHYSICS
         lds_await(&s_misc[M_C_PREP], P_WAVES);
         int gsum[P_WAVES + 1];
         gsum[0] = 0;
@@ -691,6 +727,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                                s_s + 4 * BLOCK_ENVS + owner * 64, BLOCK_ENVS, s_ia + owner * 64);
         }
         lds_arrive(&s_misc[M_C_POOL], 1);
+#endif
     } else if (helpers && wave >= HELPER0) {
         const int ht = tid - HELPER0 * 64, hw = wave - HELPER0;       // helper thread / wave index
         constexpr int NHT = N_HELP * 64;
@@ -700,7 +737,6 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #else
 #define SCG_HSTAMP(SEC) do { } while (0)
 #endif
-        stage_w(A.W, 0, ht, NHT);
         SCG_HSTAMP(10);
         lds_await(&s_misc[M_C_PUBS], 64 * P_WAVES);                                    // the P waves have published s and the option ids
         SCG_HSTAMP(11);
@@ -723,22 +759,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         {
             uint64_t mk[P_WAVES][NACT];
             int at[P_WAVES];
-#pragma unroll
-            for (int h = 0; h < P_WAVES; ++h) at[h] = 64 * h + lane < nb ? (int)s_a[64 * h + lane] : -1;
-            int off = 0;
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-                int rl = 0, nbq = 0;
-#pragma unroll
-                for (int h = 0; h < P_WAVES; ++h) {
-                    mk[h][a] = __ballot(at[h] == a);
-                    rl += __popcll(mk[h][a]);
-                    const int lim = mB - 64 * h;                                      // positions below mB belong to option kB
-                    const uint64_t pre = lim >= 64 ? ~0ull : (lim > 0 ? ((1ull << lim) - 1ull) : 0ull);
-                    nbq += __popcll(mk[h][a] & pre);
-                }
-                run_len[a] = rl; run_off[a] = off; nBa[a] = nbq; off += rl;
-            }
+            u1_geometry(mk, at);
             if (hw == 0) {
                 const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -755,7 +776,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
         SCG_HSTAMP(14);
-        if (!(A.learn & 2u)) run_u1_dyn();                        // (SPEC §5.4: with the baseline cache the merged pass needs no U1)
+        run_u1_dyn();
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
 #endif
@@ -765,20 +786,20 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         decide_b();
         if (lane == 0) { s_misc[M_KB] = kB; s_misc[M_MB] = mB; }
     }
+#ifdef SCG_DIAG_NO_PHYSICS
+    if (helpers && wave < HELPER0) {                    // (diagnostic) with no physics to run, waves 0..HELPER0-1 join the helpers' U1
+        lds_await(&s_misc[M_C_HELP], N_HELP);
+        mB = s_misc[M_MB];
+        uint64_t mk[P_WAVES][NACT];
+        int at[P_WAVES];
+        u1_geometry(mk, at);
+        run_u1_dyn();
+    }
+#endif
     if (helpers) { if ((unsigned)(wave - LIST0) < (unsigned)LIST_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_LIST); else __builtin_amdgcn_s_setprio(0); }
     block_lds_sync();
 
     SCG_STAMP(0);   // phase P
-    // SPEC §5.4: the cached Q(s, a) of the merged pass's items, from env position (phase P) to update-list position (U2 reads them
-    // there, where U1 would have put them); s_maxq is rewritten by E only behind two more barriers
-    if (MODE == MODE_FUSED && (A.learn & 2u)) {
-        const int li = tid - (THREADS - BLOCK_ENVS);
-        if (li >= 0 && li < nb) {
-            const int il = s_ulist[li];
-            s_qsa[li] = s_maxq[il];
-            s_qsa[BLOCK_ENVS + li] = s_maxq[BLOCK_ENVS + il];
-        }
-    }
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s_next (and of s where no helper did it)
     for (int u = tid; u < BLOCK_ENVS * 8; u += THREADS) {     // thread -> (state sg, env i, variable d): four consecutive lanes write one env's 32 bytes
         const int i = (u >> 2) & (BLOCK_ENVS - 1), d = u & 3, sg = u / (4 * BLOCK_ENVS);      // (one lane per env and variable 64 bytes apart was a 32-way bank conflict)
@@ -849,7 +870,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 s_rk[ft] = rk; s_ck[ft] = cont;
             }
-            evA = (on == kA) || (up && cont > 0.0f) || (MODE == MODE_FUSED && (A.learn & 4u) && kA == 0);      // (SPEC §5.4: the cache takes Q_0 of EVERY s_next)
+            evA = (on == kA) || (up && cont > 0.0f);
             if (kBp >= 1) evB = (on == kBp) || (ot == kBp && A.learn && s_co[ft] > 0.0f);
             at = s_a[ft];
             s_ev[ft] = (uint8_t)((evA ? 1 : 0) | (evB ? 2 : 0));
@@ -1041,15 +1062,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 contract(v * W_FLOATS, B, qo, n16, g, w4, w8, ab_lane);
                 if (out_lane && have && ((s_ev[il] >> v) & 1)) {
                     const int kv = v ? kBp : kA;
-                    if (MODE == MODE_FUSED) {             // into the env's result line; commit_row writes qcache (and, SPEC §5.4, the baseline cache)
-                        float4 *orec = A.outrec + (size_t)(e0 + il) * OREC;
+                    if (MODE == MODE_FUSED) {             // into the env's result line; commit_row writes qcache
                         if (s_on[il] == kv) {
+                            float4 *orec = A.outrec + (size_t)(e0 + il) * OREC;
                             orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
                             orec[3].x = qo[4];
-                        }
-                        if ((A.learn & 4u) && kv == 0) {  // Q_0(s_next, .) of EVERY env
-                            orec[4] = make_float4(qo[0], qo[1], qo[2], qo[3]);
-                            orec[5].x = qo[4];
                         }
                     } else if (s_on[il] == kv) {
 #pragma unroll

@@ -1,6 +1,6 @@
 """One-off randomised parity sweep beyond the fixed cases of tests/test_gpu_stress.py: N random configurations (batch size,
 options, map incl. the crowded synthetic ones, masks, option graph, epsilon, seeds), 14-step fused rollouts with acting-only
-steps in between, every output compared bit for bit with the CPU oracle.   Usage: [FUZZ_CACHED=1] [FUZZ_BLOCK=64|128] python tests/fuzz_parity.py [N] [seed0]"""
+steps in between, every output compared bit for bit with the CPU oracle.   Usage: [FUZZ_BLOCK=64|128] python tests/fuzz_parity.py [N] [seed0]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]   # (lives under tests/: it uses the CPU oracle, the checker)
@@ -9,11 +9,9 @@ import test_gpu_stress as T
 from util import dense_map, hub_map
 import gpu_util, skill_chaining_with_graphs_amd as scg
 
-# FUZZ_CACHED=1: SPEC §5.4's cached baseline on both sides; FUZZ_BLOCK=64|128: the small-block builds of both sides
+# FUZZ_BLOCK=64|128: the small-block builds of both sides
 if os.environ.get("FUZZ_BLOCK"):
     gpu_util.set_block_envs(int(os.environ["FUZZ_BLOCK"]))
-if os.environ.get("FUZZ_CACHED"):
-    gpu_util.set_cached_baseline(True)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 rng = np.random.default_rng(seed0)
@@ -32,5 +30,5 @@ for c in range(n_cases):
     except AssertionError as e:
         print(f"MISMATCH case {c}: n={n} nopt={nopt} map={mp} seed={seed}: {str(e)[:200]}", flush=True)
 print(f"{ok} of {n_cases} random configurations bit-exact (seed0 {seed0}"
-      + (", cached baseline" if os.environ.get("FUZZ_CACHED") else "") + (f", {os.environ['FUZZ_BLOCK']}-env blocks" if os.environ.get("FUZZ_BLOCK") else "") + ")")
+      + (f", {os.environ['FUZZ_BLOCK']}-env blocks" if os.environ.get("FUZZ_BLOCK") else "") + ")")
 sys.exit(0 if ok == n_cases else 1)

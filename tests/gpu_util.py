@@ -22,40 +22,6 @@ def set_block_envs(block_envs=None):
     sc_oracle.use_block_envs(block_envs or 256)
 
 
-_CACHED = False           # SPEC §5.4: every make_pair() pair runs with the cached baseline on both sides
-
-
-def set_cached_baseline(on=False):
-    global _CACHED
-    _CACHED = bool(on)
-
-
-def _couple_cached(ctx, orc):
-    """Both sides in SPEC §5.4's mode. The library knows by itself when its cache is valid (the previous call was a learning
-    step with the flag and nothing was invalidated since); the oracle is TOLD, from what the test did to the context: the parity
-    tests call the two sides in either order within a step, so the oracle's step t looks at what the context's step t - 1 was."""
-    ctx.enable_cached_baseline()
-    orc.set_cached_baseline(True)
-    log = {"learn": {}, "invalid_from": set(), "last_t": -1}
-    real_step, real_inv, real_orc_step = ctx.step, ctx.invalidate_order, orc.step
-
-    def step(st, W, clf, enabled_mask, t, learn=True, apply=True):
-        log["learn"][t] = bool(learn)
-        r = real_step(st, W, clf, enabled_mask, t, learn=learn, apply=apply)      # (may invalidate by itself — a new state object — BEFORE it launches: that voids step t, not t + 1)
-        log["last_t"] = max(log["last_t"], t)
-        return r
-
-    def invalidate_order():
-        log["invalid_from"].add(log["last_t"] + 1)         # the cache is void for the step that comes next
-        return real_inv()
-
-    def orc_step(st, W, clf, t, enabled_mask=None):
-        use = log["learn"].get(t - 1, False) and t not in log["invalid_from"]
-        return real_orc_step(st, W, clf, t, enabled_mask=enabled_mask, use_cache=use)
-
-    ctx.step, ctx.invalidate_order, orc.step = step, invalidate_order, orc_step
-
-
 def make_pair(map_name, n_envs, n_options=0, seed=0, env_id_base=0, enabled_mask=0, **hp):
     m = scg.load_map(map_name)
     kw = dict(HP)
@@ -64,8 +30,6 @@ def make_pair(map_name, n_envs, n_options=0, seed=0, env_id_base=0, enabled_mask
     assert ctx.block_envs == (_BLOCK_ENVS or 256) == sc_oracle.lib().sco_block_envs()
     orc = sc_oracle.Oracle(m, SCALE, n_envs=n_envs, n_options=n_options, seed=seed, env_id_base=env_id_base,
                            enabled_mask=enabled_mask, n_threads=8, **kw)
-    if _CACHED:
-        _couple_cached(ctx, orc)
     return ctx, orc, m
 
 

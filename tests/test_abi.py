@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load_library()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.scg_abi_version() == 4
+    assert lib.scg_abi_version() == 5
     assert lib.scg_strerror(0) == b"ok" and b"invalid" in lib.scg_strerror(-1)
 
 
@@ -63,7 +63,7 @@ def test_every_block_geometry_build_exports_the_abi_and_reports_its_block(pkg):
             lib = _lib.load(b)
             for name in declared_symbols():
                 assert hasattr(lib, name), (b, name)
-            assert lib.scg_block_envs() == b and lib.scg_abi_version() == 4
+            assert lib.scg_block_envs() == b and lib.scg_abi_version() == 5
             O.use_block_envs(b)
             assert O.lib().sco_block_envs() == b
     finally:

@@ -197,71 +197,3 @@ def test_skill_graph_parents_generalise_the_chain():
     st["x"][0], st["y"][0] = 0.8, 0.72               # inside I_1 only: not option 2's target (the goal is) -> 2 fails, 1 selected
     G, n_k = orc.step(st, W, clf, 2)
     assert st["option_id"][0] == 1 and G[2, st["action"][0], 0] == pytest.approx(-5.0)
-
-
-def test_cached_baseline_uses_the_previous_steps_evaluation():
-    """SPEC §5.4 against a float64 restatement, one env: step 0 is exact and fills the caches; in step 1 the TD error's baseline is
-    Q(s_1, a_1) AS STEP 0 EVALUATED IT (under the weights before step 0's update), not under the current weights."""
-    orc, m = make_oracle("pinball_simple", n_envs=1, n_options=0, seed=7, epsilon=0.0, alpha=0.05)
-    orc.set_cached_baseline(True)
-    st = sc_oracle.new_state(1, m)
-    W = random_weights(1, 0)
-    clf = np.zeros((1, 8), np.float32)
-    st["qcache"][:, 0] = orc.q_values(st["x"], st["y"], st["vx"], st["vy"], W[0])[:, 0]
-    W0 = W.copy()
-    G, n_k = orc.step(st, W, clf, t=0)                         # exact (nothing cached yet), leaves Q_{W0}(s_1, .) in qcache
-    orc.apply(W, G, n_k)
-    assert not np.array_equal(W, W0)
-    s1 = [st[k].copy() for k in ("x", "y", "vx", "vy")]
-    cached_q = st["qcache"][:, 0].copy()
-    assert np.allclose(cached_q, W0[0].astype(np.float64) @ fourier_reference(*s1)[0], atol=2e-4)
-    assert np.array_equal(orc.q0cache[:, 0], cached_q)         # the root's line of every env also goes to the baseline cache
-    a1 = int(np.argmax(cached_q))
-    G1, n1 = orc.step(st, W, clf, t=1)                         # cached
-    assert n1.tolist() == [1] and st["action"][0] == a1 and st["done"][0] == 0
-    phi_s = fourier_reference(*s1)[0]
-    phi_n = fourier_reference(st["x"], st["y"], st["vx"], st["vy"])[0]
-    W64 = W[0].astype(np.float64)
-    target = st["reward"][0] + HP["gamma"] * np.max(W64 @ phi_n)
-    delta_cached = target - float(cached_q[a1])
-    delta_exact = target - W64[a1] @ phi_s
-    assert abs(delta_cached - delta_exact) > 1e-3              # (the two rules differ measurably here: alpha = 0.05)
-    assert np.allclose(G1[0, a1], delta_cached * phi_s, rtol=1e-4, atol=1e-4)
-    assert not np.allclose(G1[0, a1], delta_exact * phi_s, rtol=1e-4, atol=1e-4)
-    # an explicit "this step is exact" (what a caller says after an acting-only step or an outside write) gives the other rule
-    orc2, _ = make_oracle("pinball_simple", n_envs=1, n_options=0, seed=7, epsilon=0.0, alpha=0.05)
-    st2 = sc_oracle.new_state(1, m)
-    W2 = random_weights(1, 0)
-    st2["qcache"][:, 0] = orc2.q_values(st2["x"], st2["y"], st2["vx"], st2["vy"], W2[0])[:, 0]
-    g, n = orc2.step(st2, W2, clf, t=0); orc2.apply(W2, g, n)
-    g_exact, _ = orc2.step(st2, W2, clf, t=1)
-    assert np.allclose(g_exact[0, a1], delta_exact * phi_s, rtol=1e-4, atol=1e-4)
-
-
-def test_cached_baseline_inside_an_option_takes_the_roots_value_from_the_baseline_cache():
-    """An env that runs option 1 (the block's prefix option): the option's own item takes its baseline from qcache (the option's
-    values), the ROOT's item for the same transition from q0cache (the root's values at the same state) — SPEC §5.4."""
-    orc, m = make_oracle("pinball_simple", n_envs=1, n_options=1, seed=3, epsilon=0.0, alpha=0.05, enabled_mask=0b10)
-    orc.set_cached_baseline(True)
-    st = sc_oracle.new_state(1, m)
-    clf = np.zeros((2, 8), np.float32)
-    clf[1] = disc_weights(float(st["x"][0]), float(st["y"][0]), 0.45)       # the env sits well inside option 1's initiation set
-    W = random_weights(2, 5)
-    st["option_id"][0] = 1
-    st["qcache"][:, 0] = orc.q_values(st["x"], st["y"], st["vx"], st["vy"], W[1])[:, 0]
-    G, n_k = orc.step(st, W, clf, t=0)
-    W_before = W.copy()
-    orc.apply(W, G, n_k)
-    assert st["option_id"][0] == 1 and n_k.tolist() == [1, 1]                # still in the option; root and option both updated
-    s1 = [st[k].copy() for k in ("x", "y", "vx", "vy")]
-    phi_s = fourier_reference(*s1)[0]
-    q_opt, q_root = st["qcache"][:, 0].copy(), orc.q0cache[:, 0].copy()
-    assert np.allclose(q_opt, W_before[1].astype(np.float64) @ phi_s, atol=2e-4)
-    assert np.allclose(q_root, W_before[0].astype(np.float64) @ phi_s, atol=2e-4)
-    a1 = int(np.argmax(q_opt))
-    G1, n1 = orc.step(st, W, clf, t=1)
-    assert st["action"][0] == a1 and n1.tolist() == [1, 1]
-    phi_n = fourier_reference(st["x"], st["y"], st["vx"], st["vy"])[0]
-    cont_root = 0.0 if st["done"][0] else HP["gamma"]
-    tgt_root = st["reward"][0] + cont_root * np.max(W[0].astype(np.float64) @ phi_n)
-    assert np.allclose(G1[0, a1], (tgt_root - float(q_root[a1])) * phi_s, rtol=1e-4, atol=2e-4)

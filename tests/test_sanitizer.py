@@ -22,7 +22,7 @@ import skill_chaining_with_graphs_amd as scg
 from skill_chaining_with_graphs_amd._lib import ScgConfig
 lib = scg.load_library()
 assert scg.LIB_PATH.endswith("libscg_hip_hostasan.so")
-assert lib.scg_abi_version() == 4 and lib.scg_block_envs() == 256
+assert lib.scg_abi_version() == 5 and lib.scg_block_envs() == 256
 assert lib.scg_strerror(0) == b"ok" and lib.scg_strerror(-4).startswith(b"call order") and lib.scg_strerror(77) == b"unknown status"
 ctx = C.c_void_p()
 bad = [dict(n_envs=0), dict(n_options=9), dict(fourier_order=3), dict(device=-1)]

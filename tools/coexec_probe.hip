@@ -21,9 +21,11 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr unsigned long long WINDOW = 300000;      // shader cycles per measurement
 constexpr int ROW = 260;
 
-enum Role { IDLE = 0, M1, M3, M6, M12, M6_LDS, V_FMA8, V_B1, V_B2, V_B3, V_B1_ST, V_B2_ST, N_ROLES };
+enum Role { IDLE = 0, M1, M3, M6, M12, M6_LDS, V_FMA8, V_B1, V_B2, V_B3, V_B1_ST, V_B2_ST, X_FMA2, X_FMA4, X_FMA6, X_FMA8, X_B36, X_B24, N_ROLES };
 static const char *role_name[N_ROLES] = {"idle", "MFMA 1 acc", "MFMA 3 acc", "MFMA 6 acc", "MFMA 12 acc", "MFMA 6 acc + ds_read/waitcnt per 12",
-                                         "v_fma x8 chains", "build ILP1", "build ILP2", "build ILP3", "build ILP1 + ds_write", "build ILP2 + ds_write"};
+                                         "v_fma x8 chains", "build ILP1", "build ILP2", "build ILP3", "build ILP1 + ds_write", "build ILP2 + ds_write",
+                                         "ONE wave: MFMA + 2 v_fma each", "ONE wave: MFMA + 4 v_fma each", "ONE wave: MFMA + 6 v_fma each", "ONE wave: MFMA + 8 v_fma each",
+                                         "ONE wave: 36 MFMA + 1 build", "ONE wave: 24 MFMA + 1 build"};
 // vector instructions per unit of a role (counted from the source: mul/add/sub of the complex products; checked against the ISA)
 static int valu_per_unit(int r) {
     switch (r) {
@@ -33,12 +35,14 @@ static int valu_per_unit(int r) {
     case V_B3: return 665;
     case V_B1_ST: return 210;
     case V_B2_ST: return 405;
+    case X_FMA2: return 24; case X_FMA4: return 48; case X_FMA6: return 72; case X_FMA8: return 96;
+    case X_B36: case X_B24: return 246;
     default: return 0;
     }
 }
-static int mfma_per_unit(int r) { return (r >= M1 && r <= M6_LDS) ? 12 : 0; }
+static int mfma_per_unit(int r) { return (r >= M1 && r <= M6_LDS) ? 12 : (r >= X_FMA2 && r <= X_FMA8) ? 12 : r == X_B36 ? 36 : r == X_B24 ? 24 : 0; }
 
-struct Cfg { unsigned char role[16]; };
+struct Cfg { unsigned char role[16]; unsigned char prio[16]; };
 
 // the table build of the step kernel's item_entries, reduced to its dependency structure: per item four unit complex numbers
 // raised to powers 1..6 by repeated complex products (4 dependent chains), per power two products of pairs (ab, cd)
@@ -93,6 +97,51 @@ __device__ __forceinline__ void mfma_unit_lds(f4v (&acc)[12], const float *tab, 
     acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b2.y, acc[4], 0, 0, 0); acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, b2.y, acc[5], 0, 0, 0);
 }
 
+// ONE wave's stream holds both kinds: after every MFMA, NV independent v_fma (8 chains) — the order is pinned with
+// sched_group_barrier (1 MFMA, NV VALU, ...), so the vector instructions issue while the wave's own MFMA occupies the matrix pipe
+template <int NV>
+__device__ __forceinline__ void mix_unit(f4v (&acc)[12], float (&v)[8], float a, float b) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        acc[i % 6] = __builtin_amdgcn_mfma_f32_16x16x4f32((i & 1) ? a : b, (i & 2) ? a : b, acc[i % 6], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[(i * NV + j) & 7] = fmaf(v[(i * NV + j) & 7], a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, NV, 0); }
+}
+// ... or NM MFMAs spread over one table build (234 mul / add / sub of dependent complex products): the kernel's own ratio is 5.5 vector
+// instructions per MFMA; 36 -> 6.5, 24 -> 9.75
+template <int NM>
+__device__ __forceinline__ float mix_build_unit(f4v (&acc)[12], const float2 (&zin)[4], float a, float b, float seed) {
+    float2 z[4], p[4];
+    float keep = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { z[d] = make_float2(zin[d].x + seed, zin[d].y); p[d] = z[d]; }
+    int im = 0;
+    auto M = [&]() {        // NM / 6 MFMAs per power c, one behind every segment of the build (sched_barrier: the scheduler keeps the order)
+        __builtin_amdgcn_sched_barrier(0);
+        acc[im % 6] = __builtin_amdgcn_mfma_f32_16x16x4f32((im & 1) ? a : b, (im & 2) ? a : b, acc[im % 6], 0, 0, 0);
+        ++im;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const float2 ab = make_float2(p[0].x * p[1].x - p[0].y * p[1].y, p[0].x * p[1].y + p[0].y * p[1].x);
+        M();
+        const float2 cd = make_float2(p[2].x * p[3].x - p[2].y * p[3].y, p[2].x * p[3].y + p[2].y * p[3].x);
+        M();
+        keep += (ab.x + ab.y) + (cd.x + cd.y);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            p[d] = make_float2(p[d].x * z[d].x - p[d].y * z[d].y, p[d].x * z[d].y + p[d].y * z[d].x);
+            if (NM == 36 || d < 2) M();
+        }
+    }
+    keep += p[0].x + p[1].y + p[2].x + p[3].y;
+    return keep;
+}
+
 struct Out { float keep; unsigned units; unsigned cyc; };
 // every role's loop is its own (non-inlined) function: the ISA of one role is one symbol, countable by tools/coexec_isa_count.py
 template <int ROLE>
@@ -109,7 +158,7 @@ __device__ __attribute__((noinline)) Out run_role(const float *tab_r, float *tab
     for (int d = 0; d < 4; ++d) zin[d] = *reinterpret_cast<const float2 *>(tab_r + 2 * lane + 130 * d);
     unsigned long long t1 = t0;
     unsigned units = 0;
-    constexpr int REPS = (ROLE == V_B2_ST || ROLE == V_B3) ? 2 : 4;      // (unrolled units per loop trip: kept below the register budget)
+    constexpr int REPS = (ROLE == X_B36 || ROLE == X_B24) ? 1 : (ROLE == V_B2_ST || ROLE == V_B3) ? 2 : 4;      // (unrolled units per loop trip: kept below the register budget)
 #pragma unroll 1
     for (;;) {
 #pragma unroll
@@ -131,6 +180,12 @@ __device__ __attribute__((noinline)) Out run_role(const float *tab_r, float *tab
             if (ROLE == V_B3) keep += build_unit<3, false>(tab_w, zin, wave, lane, keep * 1e-30f);
             if (ROLE == V_B1_ST) keep += build_unit<1, true>(tab_w, zin, wave, lane, 1e-3f * ((units + rep) & 7));
             if (ROLE == V_B2_ST) keep += build_unit<2, true>(tab_w, zin, wave, lane, 1e-3f * ((units + rep) & 7));
+            if (ROLE == X_FMA2) mix_unit<2>(acc, v, a, b);
+            if (ROLE == X_FMA4) mix_unit<4>(acc, v, a, b);
+            if (ROLE == X_FMA6) mix_unit<6>(acc, v, a, b);
+            if (ROLE == X_FMA8) mix_unit<8>(acc, v, a, b);
+            if (ROLE == X_B36) keep += mix_build_unit<36>(acc, zin, a, b, keep * 1e-30f);
+            if (ROLE == X_B24) keep += mix_build_unit<24>(acc, zin, a, b, keep * 1e-30f);
         }
         units += REPS;
         t1 = __builtin_amdgcn_s_memtime();
@@ -150,6 +205,12 @@ __global__ __launch_bounds__(1024) void k(const Cfg cfg, unsigned *units_out, un
     const int role = __builtin_amdgcn_readfirstlane((int)cfg.role[wave]);
     for (int i = threadIdx.x; i < 2 * 72 * ROW; i += 1024) lds[i] = 0.6f + 1e-4f * (i & 1023);
     __syncthreads();
+    switch (__builtin_amdgcn_readfirstlane((int)cfg.prio[wave])) {      // (s_setprio takes an immediate)
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+    }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     Out o = {0.0f, 0u, 0u};
     switch (role) {
@@ -164,6 +225,12 @@ __global__ __launch_bounds__(1024) void k(const Cfg cfg, unsigned *units_out, un
     case V_B3: o = run_role<V_B3>(tab_r, tab_w, wave, lane, t0); break;
     case V_B1_ST: o = run_role<V_B1_ST>(tab_r, tab_w, wave, lane, t0); break;
     case V_B2_ST: o = run_role<V_B2_ST>(tab_r, tab_w, wave, lane, t0); break;
+    case X_FMA2: o = run_role<X_FMA2>(tab_r, tab_w, wave, lane, t0); break;
+    case X_FMA4: o = run_role<X_FMA4>(tab_r, tab_w, wave, lane, t0); break;
+    case X_FMA6: o = run_role<X_FMA6>(tab_r, tab_w, wave, lane, t0); break;
+    case X_FMA8: o = run_role<X_FMA8>(tab_r, tab_w, wave, lane, t0); break;
+    case X_B36: o = run_role<X_B36>(tab_r, tab_w, wave, lane, t0); break;
+    case X_B24: o = run_role<X_B24>(tab_r, tab_w, wave, lane, t0); break;
     default: break;
     }
     sink[blockIdx.x * 1024 + threadIdx.x] = o.keep;
@@ -186,9 +253,16 @@ static Res run(const Cfg &c) {
     }
     return {m / (n * 4.0), v / (n * 4.0)};      // 4 SIMDs per CU; wave w runs on SIMD w % 4, so per-SIMD = sum over its waves
 }
-static Cfg make(int nm, int mrole, int nv, int vrole) {      // nm MFMA waves + nv vector waves on EVERY SIMD (waves w, w+4, w+8, w+12 share one)
+// nm MFMA waves + nv vector waves on EVERY SIMD (waves w, w+4, w+8, w+12 share one); vfirst: the vector waves take the lower wave ids
+// (the older waves of the SIMD); vprio / mprio: s_setprio of the two kinds
+static Cfg make(int nm, int mrole, int nv, int vrole, bool vfirst = false, int vprio = 0, int mprio = 0) {
     Cfg c; memset(&c, 0, sizeof c);
-    for (int s = 0; s < 4; ++s) { int slot = 0; for (int i = 0; i < nm; ++i) c.role[s + 4 * slot++] = (unsigned char)mrole; for (int i = 0; i < nv; ++i) c.role[s + 4 * slot++] = (unsigned char)vrole; }
+    for (int s = 0; s < 4; ++s) {
+        int slot = 0;
+        if (vfirst) for (int i = 0; i < nv; ++i) { c.role[s + 4 * slot] = (unsigned char)vrole; c.prio[s + 4 * slot++] = (unsigned char)vprio; }
+        for (int i = 0; i < nm; ++i) { c.role[s + 4 * slot] = (unsigned char)mrole; c.prio[s + 4 * slot++] = (unsigned char)mprio; }
+        if (!vfirst) for (int i = 0; i < nv; ++i) { c.role[s + 4 * slot] = (unsigned char)vrole; c.prio[s + 4 * slot++] = (unsigned char)vprio; }
+    }
     return c;
 }
 
@@ -221,5 +295,23 @@ int main() {
     for (int mr : {M1, M3, M6, M12}) { line(2, mr, 2, V_B1); line(2, mr, 2, V_FMA8); }
     printf("--- LDS on either side (2 + 2)\n");
     line(2, M6, 2, V_B1_ST); line(2, M6_LDS, 2, V_B1); line(2, M6_LDS, 2, V_B1_ST); line(2, M6_LDS, 2, V_B2_ST); line(3, M6_LDS, 1, V_B1_ST); line(1, M6_LDS, 3, V_B1_ST);
+    printf("--- who wins the issue port: wave age (vector waves = the lower wave ids) and s_setprio\n");
+    auto line2 = [&](int nm, int mr, int nv, int vr, bool vfirst, int vprio, int mprio) {
+        const Res r = run(make(nm, mr, nv, vr, vfirst, vprio, mprio));
+        printf("%d x %-22s + %d x %-22s %-22s prio M %d V %d | %5.1f %% (alone %5.1f %%) | %.3f (alone %.3f = %3.0f %% kept) | %.2f\n", nm, role_name[mr], nv, role_name[vr],
+               vfirst ? "vector waves older" : "MFMA waves older", mprio, vprio, 100 * r.mfma_busy, 100 * m_solo[mr][nm], r.valu_ipc, v_solo[vr][nv], 100 * r.valu_ipc / v_solo[vr][nv],
+               r.mfma_busy + r.valu_ipc / v_solo[vr][4]);
+    };
+    for (int vr : {V_FMA8, V_B1}) {
+        line2(2, M6, 2, vr, true, 0, 0); line2(2, M6, 2, vr, false, 3, 0); line2(2, M6, 2, vr, true, 3, 0); line2(2, M6, 2, vr, false, 0, 3);
+        line2(1, M6, 3, vr, true, 0, 0); line2(1, M6, 3, vr, true, 3, 0); line2(1, M6, 1, vr, true, 3, 0); line2(3, M6, 1, vr, true, 3, 0);
+    }
+    printf("--- both kinds in ONE wave's instruction stream (n waves per SIMD all running the mixed stream)\n");
+    for (int xr : {X_FMA2, X_FMA4, X_FMA6, X_FMA8, X_B36, X_B24})
+        for (int n = 1; n <= 4; ++n) {
+            const Res r = run(make(n, xr, 0, 0));
+            printf("%d x %-32s | pipe busy %5.1f %% | %.3f vector instr / cycle (%.0f %% of the 4-wave solo rate of that stream) | combined %.2f\n", n, role_name[xr], 100 * r.mfma_busy, r.valu_ipc,
+                   100 * r.valu_ipc / v_solo[xr >= X_B36 ? V_B1 : V_FMA8][4], r.mfma_busy + r.valu_ipc / v_solo[xr >= X_B36 ? V_B1 : V_FMA8][4]);
+        }
     return 0;
 }

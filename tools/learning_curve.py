@@ -9,10 +9,10 @@ ap.add_argument("--map", default="pinball_simple"); ap.add_argument("--envs", ty
 ap.add_argument("--alpha", type=float, default=0.02); ap.add_argument("--eps", type=float, default=0.05)
 ap.add_argument("--gamma", type=float, default=0.99); ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--chunk", type=int, default=500); ap.add_argument("--maxep", type=int, default=2000)
-ap.add_argument("--seed", type=int, default=1); ap.add_argument("--cached-baseline", action="store_true", help="SPEC 5.4")
+ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
-ag = SkillChainingAgent(a.map, a.envs, 0, seed=a.seed, alpha=a.alpha, epsilon=a.eps, gamma=a.gamma, max_episode_steps=a.maxep, cached_baseline=a.cached_baseline)
-print(f"# learning_curve map {a.map} envs {a.envs} alpha {a.alpha} eps {a.eps} gamma {a.gamma} seed {a.seed}{' CACHED BASELINE (SPEC 5.4)' if a.cached_baseline else ''}", flush=True)
+ag = SkillChainingAgent(a.map, a.envs, 0, seed=a.seed, alpha=a.alpha, epsilon=a.eps, gamma=a.gamma, max_episode_steps=a.maxep)
+print(f"# learning_curve map {a.map} envs {a.envs} alpha {a.alpha} eps {a.eps} gamma {a.gamma} seed {a.seed}", flush=True)
 for it in range(a.iters):
     goals = torch.zeros((), device="cuda"); touts = torch.zeros((), device="cuda")
     for _ in range(a.chunk):

@@ -3,7 +3,7 @@ Usage: python tools/stamp_report.py [--options N] [--steps K]   (needs `make -C 
 import argparse, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
-ap = argparse.ArgumentParser(); ap.add_argument("--options", type=int, default=5); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--cached-baseline", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--options", type=int, default=5); ap.add_argument("--steps", type=int, default=50)
 args = ap.parse_args()
 from skill_chaining_with_graphs_amd import _lib
 _lib.LIB_PATH = os.environ.get("SCG_STAMPS_LIB") or os.path.join(os.path.dirname(_lib.LIB_PATH), "libscg_hip_stamps.so")   # SCG_STAMPS_LIB: a variant stamps build
@@ -11,7 +11,7 @@ import numpy as np, torch
 import bench
 from skill_chaining_with_graphs_amd import SkillChainingAgent
 n = 65536
-agent = SkillChainingAgent(bench.MAP, n, args.options, seed=0, cached_baseline=args.cached_baseline, **bench.HP)
+agent = SkillChainingAgent(bench.MAP, n, args.options, seed=0, **bench.HP)
 agent.clf.copy_(torch.as_tensor(bench.chain_discs(agent.map, args.options)))
 for k in range(1, args.options + 1): agent.enable_option(k)
 agent.init_weights(std=1e-3); agent.domain.reset_random(seed=1000)
