@@ -235,18 +235,19 @@ typedef struct {
     int env;      /* block-local env index */
     int upd, tgt, cache;
     float r, cont;
+    int want;     /* SPEC §4.2 value-gated entry: evaluate Q(s_next, .) although the item neither bootstraps nor caches */
     int boot;     /* SPEC §4.2 exit rule: the target is r + gamma * boot_v (the root's max_a Q_0(s_next, a)) */
     float boot_v, boot_g;
 } td_item;
 
 static void block_vf_pass(const float *Wk, int n_items, const td_item *items, const env_rec *rec,
                           const st_tab *tab_s, const st_tab *tab_n, float *qcache, int qstride,
-                          const int *env_of, float *Pout, int *n_upd, float *maxq_env) {
+                          const int *env_of, float *Pout, int *n_upd, float *maxq_env, int maxq_cache_only, float (*qn_env)[NACT]) {
     /* evaluations (order-free: each item's Q values depend on nothing else) */
     float *maxq = (float *)calloc((size_t)(n_items > 0 ? n_items : 1), sizeof(float));
     for (int i = 0; i < n_items; ++i) {
         const td_item *it = &items[i];
-        if (it->tgt || it->cache) {
+        if (it->tgt || it->cache || it->want) {
             float qn[NACT];
             for (int a = 0; a < NACT; ++a) qn[a] = q_value(Wk + a * NF, a, &tab_n[it->env]);
             if (it->cache)
@@ -254,7 +255,8 @@ static void block_vf_pass(const float *Wk, int n_items, const td_item *items, co
             float m = qn[0];
             for (int a = 1; a < NACT; ++a) m = fmaxf(m, qn[a]);
             maxq[i] = m;
-            if (maxq_env) maxq_env[it->env] = m;
+            if (maxq_env && (!maxq_cache_only || it->cache)) maxq_env[it->env] = m;
+            if (qn_env) for (int a = 0; a < NACT; ++a) qn_env[it->env][a] = qn[a];
         }
     }
     /* SPEC §5 accumulation: per action, the run of update items in block order, in groups of four (the last
@@ -332,13 +334,13 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
             for (int d = 0; d < 4; ++d) { rec[i].s[d] = s4[d][e]; rec[i].sn[d] = sn4[d][e]; }
             rec[i].a = action[e];
             items[i].env = i; items[i].upd = 1; items[i].tgt = cont[e] > 0.0f; items[i].cache = 0;
-            items[i].boot = 0; items[i].boot_v = 0.0f; items[i].boot_g = 0.0f;
+            items[i].want = 0; items[i].boot = 0; items[i].boot_v = 0.0f; items[i].boot_g = 0.0f;
             items[i].r = r[e]; items[i].cont = cont[e];
             state_tables(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], tab_s[i].AB, tab_s[i].CD);
             if (items[i].tgt)
                 state_tables(rec[i].sn[0], rec[i].sn[1], rec[i].sn[2], rec[i].sn[3], tab_n[i].AB, tab_n[i].CD);
         }
-        block_vf_pass(Wk, nb, items, rec, tab_s, tab_n, dummy_q, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b], NULL);
+        block_vf_pass(Wk, nb, items, rec, tab_s, tab_n, dummy_q, 0, NULL, P + (size_t)b * NACT * NF, &cnts[b], NULL, 0, NULL);
         free(rec); free(items); free(tab_s); free(tab_n);
     }
     int total = 0;
@@ -432,6 +434,9 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         unsigned gs[SCO_BLOCK_ENVS];
         float rg[SCO_BLOCK_ENVS][8], cg[SCO_BLOCK_ENVS][8];
         float rootmax[SCO_BLOCK_ENVS];           /* max_a Q_0(s_next, a) of every env whose episode goes on (root pass) */
+        float candmax[SCO_BLOCK_ENVS];           /* SPEC §4.2 value-gated entry: max_a Q_cand(s_next, a) of an env about to ENTER option cand */
+        float rootq[SCO_BLOCK_ENVS][NACT];
+        int entering[SCO_BLOCK_ENVS];
         unsigned xo[SCO_BLOCK_ENVS], xg[SCO_BLOCK_ENVS];   /* exit-rule flags: bit 0 own option ended (episode goes on), bit 1 by success; xg: per gestating k, 2 bits each */
         st_tab *tab_s = (st_tab *)malloc(sizeof(st_tab) * nb);
         st_tab *tab_n = (st_tab *)malloc(sizeof(st_tab) * nb);
@@ -493,6 +498,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                     on = k; break;
                 }
             o_t[i] = o; o_n[i] = on;
+            entering[i] = p->select_rule == 1 && !keep && on >= 1; candmax[i] = 0.0f;
             r0[i] = rew; c0[i] = dn ? 0.0f : p->gamma;
             /* SPEC §4.4: gestating options that hold the ENTRY state in their initiation set learn off-policy from this
              * transition, as if the env had been running them (no time-out); their successes are counted */
@@ -540,9 +546,10 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 int gst = !own && ((gs[i] >> k) & 1u);
                 int upd = own || gst;
                 int cache = (o_n[i] == k);
-                if (!upd && !cache) continue;
+                int want = (k == 0) && entering[i];                             /* the root's value of s_next, to compare with the option's */
+                if (!upd && !cache && !want) continue;
                 float cont = (k == 0) ? c0[i] : (gst ? cg[i][k] : co[i]);
-                items[m].env = i; items[m].upd = upd; items[m].cache = cache;
+                items[m].env = i; items[m].upd = upd; items[m].cache = cache; items[m].want = want;
                 items[m].tgt = upd && cont > 0.0f;
                 items[m].r = (k == 0) ? r0[i] : (gst ? rg[i][k] : ro[i]);
                 items[m].cont = cont;
@@ -554,7 +561,16 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 ++m;
             }
             block_vf_pass(W + (size_t)k * NACT * NF, m, items, rec, tab_s, tab_n, qcache, N, env_of,
-                          P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k], k == 0 ? rootmax : NULL);
+                          P + ((size_t)b * n_vf + k) * NACT * NF, &cnts[(size_t)b * n_vf + k], k == 0 ? rootmax : candmax, k != 0, k == 0 ? rootq : NULL);
+        }
+        /* SPEC §4.2 value-gated entry: an env about to enter option k does so only if the option promises at least what the root
+         * does from there, max_a Q_k(s_next, a) >= max_a Q_0(s_next, a) (both as evaluated above, under this step's weights);
+         * otherwise it stays with the root, whose values of s_next become its qcache */
+        for (int i = 0; i < nb; ++i) {
+            if (!entering[i] || candmax[i] >= rootmax[i]) continue;
+            int e = env_of[i];
+            option_id[e] = 0;
+            for (int a = 0; a < NACT; ++a) qcache[(size_t)a * N + e] = rootq[i][a];
         }
         free(tab_s); free(tab_n); free(items);
     }

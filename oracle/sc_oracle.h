@@ -52,6 +52,8 @@ typedef struct {
      * the env goes next, gamma * max_a Q_0(s_next, a), success ends with r + r_option_success; 2: success bootstraps too;
      * 3 (experiment): as 0 with a pure subgoal reward — the option's reward is r_option_success on success and 0 otherwise (no step costs) */
     int32_t exit_rule;
+    /* SPEC §4.2 option selection: 0 = forced (an env inside an initiation set must run the option); 1 = value-gated entry */
+    int32_t select_rule;
 } sco_params;
 
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

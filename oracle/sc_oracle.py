@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("ring_len", C.c_int32),
         ("parents", C.c_int32 * 8),
         ("gest_mask", C.c_uint32), ("gest_succ", C.c_void_p),
-        ("exit_rule", C.c_int32),
+        ("exit_rule", C.c_int32), ("select_rule", C.c_int32),
     ]
 
 

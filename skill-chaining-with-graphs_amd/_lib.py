@@ -86,6 +86,20 @@ EXPORTED_SYMBOLS = tuple(_SIGS)
 BLOCK_ENVS_DEFAULT = 256
 BLOCK_ENVS_BUILDS = (64, 128, 256)     # SPEC §5 geometry is a build parameter: csrc/Makefile builds one library per value
 
+CHIP_CUS = 256            # MI355X: 8 XCDs x 32 CUs; one 16-wavefront workgroup owns a CU
+
+
+def auto_block_envs(n_envs: int) -> int:
+    """The SPEC §5 block size a context of `n_envs` envs picks when none is given: the SMALLEST build whose workgroups — one per
+    block, one per CU — still fit the chip in one round (a workgroup is an ~80 us latency chain whatever its size, so below 65 536
+    envs smaller blocks on more CUs win; DESIGN §3.6: 4096 envs 127 / 104 / 69 M env-steps/s at 64 / 128 / 256). Deterministic in
+    n_envs alone (the CU count is the chip's constant, not queried): a run's geometry is part of its identity like its seed."""
+    for b in BLOCK_ENVS_BUILDS:
+        if -(-int(n_envs) // b) <= CHIP_CUS:
+            return b
+    return BLOCK_ENVS_DEFAULT
+
+
 _libs = {}
 
 

@@ -6,12 +6,13 @@ named after north_star. Per-step work is one scg_step launch pair (fused kernel 
 nothing on the per-step path synchronises with or copies to the host."""
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
 
 from . import dist as _dist
-from ._lib import CLF_STRIDE, NUM_ACTIONS, NUM_FEATURES, ScgError
+from ._lib import CLF_STRIDE, NUM_ACTIONS, NUM_FEATURES, ScgError, auto_block_envs
 from .core import EnvState, ScgContext
 from .maps import PinballMap, load_map
 from .option import Option
@@ -22,6 +23,10 @@ class SkillChainingAgent:
     def __init__(self, pmap, n_envs: int, n_options: int = 0, *, device: int = 0, seed: int = 0,
                  env_id_base: int = 0, group=None, ordered_sum: bool = False, **hparams):
         self.map: PinballMap = load_map(pmap) if isinstance(pmap, str) else pmap
+        if group is not None and hparams.get("block_envs") is None and not os.environ.get("SCG_BLOCK_ENVS"):
+            # a sharded run uses ONE block geometry (it orders the partial sums of G): the ranks agree on the largest any of them
+            # would pick from its own env count (equal shards pick equal sizes anyway)
+            hparams["block_envs"] = _dist.allreduce_max_int(auto_block_envs(n_envs), group, torch.device("cuda", device))
         self.ctx = ScgContext(n_envs, n_options, self.map, device=device, seed=seed, env_id_base=env_id_base,
                               **hparams)
         dev = self.ctx.device

@@ -6,6 +6,7 @@ launch (a kernel fault can take the whole GPU host down)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -43,7 +44,9 @@ class ScgContext:
             raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")
         if not (0 <= n_options <= MAX_OPTIONS):
             raise ScgError(f"n_options must be in [0, {MAX_OPTIONS}]")
-        self.lib = _lib.load(block_envs)                     # None: the 256-env build; 64 / 128: the small-batch builds (SPEC §5 geometry)
+        if block_envs is None:                               # SPEC §5 geometry: SCG_BLOCK_ENVS pins it, else by the env count
+            block_envs = int(os.environ["SCG_BLOCK_ENVS"]) if os.environ.get("SCG_BLOCK_ENVS") else _lib.auto_block_envs(n_envs)
+        self.lib = _lib.load(block_envs)                     # one library per geometry (64 / 128 / 256 envs per block = per workgroup)
         self.block_envs = int(self.lib.scg_block_envs())
         self.n_envs, self.n_options, self.n_vf = int(n_envs), int(n_options), int(n_options) + 1
         self.device = torch.device("cuda", device)

@@ -1143,7 +1143,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         scg_destroy(c);
         return st;
     }
-#ifdef SCG_STAMPS
+#if defined(SCG_STAMPS) || defined(SCG_STAMPS_LITE)
     if (hipMalloc(&c->d_stamps, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemset(c->d_stamps, 0, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long));
 #endif
@@ -1362,7 +1362,7 @@ int scg_invalidate_order(scg_ctx *c) {
     return SCG_OK;
 }
 
-#ifdef SCG_STAMPS
+#if defined(SCG_STAMPS) || defined(SCG_STAMPS_LITE)
 extern "C" int scg_diag_stamps(scg_ctx *c, unsigned long long *host_out /*[nblk][16]*/, int32_t reset) {
     if (!c || !c->d_stamps) return SCG_ERR_STATE;
     if (host_out && hipMemcpy(host_out, c->d_stamps, (size_t)c->nblk * STAMP_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return SCG_ERR_HIP;

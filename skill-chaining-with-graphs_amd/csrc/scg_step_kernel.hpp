@@ -66,6 +66,24 @@ constexpr int LDS_BYTES = OFF_STAMP + STAMP_SLOTS * 4;
 #else
 constexpr int LDS_BYTES = OFF_MISC + 512;
 #endif
+#ifdef SCG_STAMPS_LITE
+// The light timing build (round 5): the full stamps build runs 7 % slower than the product and a change that took 3 % off ITS kernel
+// took nothing off the product's — it measures another kernel. Here four waves (an env wave, a pool wave, the first and the last
+// helper) read the clock at eight phase boundaries into scalar registers and write them out once, at the end: no LDS, no branches
+// on the way. Slots per block: [wave role 0..3][8 boundaries] cycles since the wave's kernel entry, [32] start and [33] end on the
+// 100 MHz wall clock (launch ramp across the chip).
+constexpr int STAMP_SLOTS = 48;
+#if SCG_STAMPS_LITE == 2      // variant: the env wave's eight boundaries lie INSIDE phase P (the other roles keep theirs)
+#define SCG_LITE(I) do { if (MODE == MODE_FUSED && (lite_role >= 1 || (I) == 0)) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SCG_LITEP(I) do { if (MODE == MODE_FUSED && lite_role == 0) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SCG_LITE(I) do { if (MODE == MODE_FUSED && lite_role >= 0) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SCG_LITEP(I) do { } while (0)
+#endif
+#else
+#define SCG_LITE(I) do { } while (0)
+#define SCG_LITEP(I) do { } while (0)
+#endif
 static_assert(BLOCK_ENVS / 8 <= 64, "eflag area");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget: one workgroup per CU");
 static_assert(OFF_Z1 % 16 == 0 && OFF_R % 16 == 0 && (R_TAB * 4) % 16 == 0 && (R_EDGES * 4) % 16 == 0 && (E_TAB_FLOATS * 4) % 16 == 0, "LDS alignment");
@@ -85,6 +103,7 @@ constexpr int M_KB = 75, M_MB = 76; // the block's option (value function B of t
 constexpr int M_U1CTR = 78;        // next U1 column block to take (helper waves, dynamic dealing)
 constexpr int M_ECTR = 79;         // next E unit to take (dynamic dealing)
 constexpr int M_EO = 80;           // [12] evaluation-only lists: [k] items of value function k (k = 1..5), [6 + k] their start in s_elist, [6] units in all
+constexpr int M_C_TOP = 92;         // waves without envs have put the edge and classifier tables into LDS
 constexpr int M_INTS = 128;
 static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
 
@@ -178,6 +197,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const int e0 = b * BLOCK_ENVS;
     const int nb = min(BLOCK_ENVS, A.n - e0);
     const int N = A.n;
+#ifdef SCG_STAMPS_LITE
+    const int lite_role = wave == 0 ? 0 : wave == P_WAVES ? 1 : wave == HELPER0 ? 2 : wave == WAVES - 1 ? 3 : -1;
+    unsigned long long lt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long lite_r0 = __builtin_amdgcn_s_memrealtime();
+    SCG_LITE(0);
+#endif
 #ifdef SCG_STAMPS
     unsigned *s_stamp = reinterpret_cast<unsigned *>(smem + OFF_STAMP);
     if (tid < STAMP_SLOTS) s_stamp[tid] = 0;
@@ -491,27 +516,29 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     // the entry states, build the root's update list and run U1 of both value functions under it.
     const bool helpers = MODE == MODE_FUSED && A.learn && A.k_hi >= 0;
 
-    // ------------------------------------------------------------------ kernel start
-    // Every wave issues its first global loads before anybody waits for anything (round 5): the first round trips of a launch are
-    // cold ones (4-6k cycles each), and the old start — edge table -> barrier -> perm -> state gathers on the env waves,
-    // barrier -> W_0 on the helpers — paid three of them in a row on the env waves' chain and two on the helpers'.
+    // ------------------------------------------------------------------ kernel start (round 5)
+    // The first round trips of a launch are cold ones (4-6k cycles each). The old start — edge table -> barrier -> perm -> state
+    // gathers on the env waves, barrier -> W_0 on the helpers — paid three of them in a row on the env waves' chain and two on the
+    // helpers'. Now the ONE barrier of the start stands in front of every global access (it only covers the counters' reset), every
+    // wave issues its first loads right behind it, and the edge / classifier tables — loaded by the waves without envs — are
+    // handed over through an LDS counter where they are first needed (the physics), not through a barrier.
+    if (tid < M_INTS) s_misc[tid] = (tid == M_PRESENT || tid == M_UPD) ? 1 : 0;
+    block_lds_sync();
+    SCG_LITE(1);                                            // behind the start barrier
     int e_pre = e0 + tid;                                   // env waves: this position's env
     if (MODE == MODE_FUSED) {
-        if (wave < P_WAVES && tid < nb && A.perm) e_pre = A.perm[e0 + tid];
-        // helper waves: W_0 goes to its place in region W (free during phase P) BEFORE the barrier: the barrier then waits for ONE
-        // cold round trip (W_0 beside the env waves' perm and the edge table) instead of standing between two. (Keeping W_0 in
-        // registers across the barrier instead — 14 per thread, helper waves only — sent the register allocator of the whole
-        // kernel over the edge: 27 spill / reload sites in E and U2 instead of 2.)
-        if (helpers && wave >= HELPER0) stage_w(A.W, 0, tid - HELPER0 * 64, N_HELP * 64);
+        if (wave < P_WAVES) {
+            if (tid < nb && A.perm) e_pre = A.perm[e0 + tid];
+        } else {
+            // helper waves: W_0 goes to its place in region W (free during phase P) first. (Holding it in registers across a
+            // wait instead — 14 per thread — sent the register allocator of the whole kernel over the edge: 27 spill / reload
+            // sites in E and U2 instead of 2; so did the edge table as two predicated loads per thread.)
+            if (helpers && wave >= HELPER0) stage_w(A.W, 0, tid - HELPER0 * 64, N_HELP * 64);
+            for (int i = tid - P_WAVES * 64; i < A.ms.n_edges * 8; i += THREADS - P_WAVES * 64) s_edges[i] = A.edges[i];
+            if (tid - P_WAVES * 64 < A.n_vf * CLF_STRIDE) s_clf[tid - P_WAVES * 64] = A.clf[tid - P_WAVES * 64];
+            lds_arrive(&s_misc[M_C_TOP], 1);
+        }
     }
-    if (tid < M_INTS) s_misc[tid] = (tid == M_PRESENT || tid == M_UPD) ? 1 : 0;
-    if (MODE == MODE_FUSED) {
-        // (a form with the edge loads issued together as well — two predicated loads per thread into registers — sent the register
-        //  allocator of the WHOLE kernel over the edge: 27 spill / reload sites in E and U2 instead of 2; maps up to 128 edges are one trip)
-        for (int i = tid; i < A.ms.n_edges * 8; i += THREADS) s_edges[i] = A.edges[i];
-        if (tid < A.n_vf * CLF_STRIDE) s_clf[tid] = A.clf[tid];
-    }
-    block_lds_sync();
 
     // ------------------------------------------------------------------ phase P
     if (helpers) { if (wave < P_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_P); else if (wave >= HELPER0) __builtin_amdgcn_s_setprio(SCG_PRIO_HELP); }
@@ -538,6 +565,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 s_ot[i] = 255;
             }
             lds_arrive(&s_misc[M_C_PUBS], 64);
+            SCG_LITEP(1);                                         // entry state gathered and published
             SCG_STAMP(17);                                        // P: perm + state gathers
             if (valid) {
                 // act (SPEC §2, §4.3)
@@ -559,20 +587,33 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
             SCG_STAMP(16);                                        // P: qcache gathers, Philox, action
             lds_arrive(&s_misc[M_C_PUB], 64);                                     // state, action and option id of this wave's envs are out
+            SCG_LITEP(2);
             // physics (SPEC §1.3), the whole wave together
             bool goal;
             // the envs' own wave settles free flight and lists the (env, candidate edge) pairs of the others in groups of 64;
             // the groups of ALL env waves are then dealt to waves 0..P_POOL-1
             bool par;
             float *xs_mine = s_s + 4 * BLOCK_ENVS + wave * 64;
+            lds_await(&s_misc[M_C_TOP], WAVES - P_WAVES);                         // the edge and classifier tables are in LDS
 #ifdef SCG_DIAG_NO_PHYSICS         // (diagnostic, WRONG results: prices a step kernel WITHOUT phase P's physics at its head — VERDICT r4 item 1c)
-            goal = false; par = false;
+            goal = false; par = false;                  // free flight through everything (20 fmas; keeps the batch moving so that the
+            {                                           // option / action mix of the timed workload stays what it is with physics)
+                const float DV = 0x1.99999ap-3f;
+                svx = fminf(fmaxf(a == 0 ? svx + DV : (a == 2 ? svx - DV : svx), -2.0f), 2.0f);
+                svy = fminf(fmaxf(a == 1 ? svy + DV : (a == 3 ? svy - DV : svy), -2.0f), 2.0f);
+                for (int q = 0; q < 20; ++q) { sx = fmaf(svx, A.ms.hstep, sx); sy = fmaf(svy, A.ms.hstep, sy); }
+                if (sx < 0.0f || sx > 1.0f) svx = -svx;
+                if (sy < 0.0f || sy > 1.0f) svy = -svy;
+                svx *= 0x1.fd70a4p-1f; svy *= 0x1.fd70a4p-1f;
+                sx = fminf(fmaxf(sx, 0.0f), 1.0f); sy = fminf(fmaxf(sy, 0.0f), 1.0f);
+            }
             const float rew = a == 4 ? -1.0f : -5.0f;
 #else
             const int groups = pinball_wave_prepare_any(s_edges, A.cellmask, A.ms, valid, sx, sy, svx, svy, a, goal, par,
                                                         s_pitems + wave * PITEMS, xs_mine, BLOCK_ENVS);
             if (lane == 0) s_misc[M_GROUPS + wave] = groups;
             lds_arrive(&s_misc[M_C_PREP], 1);
+            SCG_LITEP(3);                                         // own part of the physics done, pair groups listed
             SCG_STAMP(18);                                        // P: physics, own part (refinement, free flight, pair lists)
             {
                 lds_await(&s_misc[M_C_PREP], P_WAVES);
@@ -592,6 +633,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             }
             const float rew = pinball_wave_finish(par, sx, sy, svx, svy, a, goal, xs_mine, BLOCK_ENVS, s_ia + wave * 64);
 #endif
+            SCG_LITEP(4);                                         // pooled pair groups done (everybody's), results read back
             SCG_STAMP(2);                                         // P: physics, the pooled pair groups + hand-offs
             int hkey = -1;
             if (valid) {
@@ -671,6 +713,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
                                           __int_as_float(osn), __int_as_float(epn));
                 }
+                SCG_LITEP(5);
                 SCG_STAMP(19);                                        // P: bookkeeping, option logic, result line
                 if (A.ring_x) {                                       // SPEC §7: trajectory ring + events
                     const size_t row = (size_t)(ep0 & A.ring_mask) * N + e;
@@ -694,6 +737,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     rem &= ~m;
                 }
             }
+            SCG_LITEP(6);                                         // trace, events, histogram issued
         } else if (valid) {
             if (MODE == MODE_TRANS) {
                 s_s[0 * BLOCK_ENVS + i] = A.x[e]; s_s[1 * BLOCK_ENVS + i] = A.y[e];
@@ -743,6 +787,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         decide_b();
         if (hw == 0 && lane == 0) { s_misc[M_KB] = kB; s_misc[M_MB] = mB; }
         if (kB >= 1) stage_w(A.W + (size_t)kB * NACT * NF, W_FLOATS, ht, NHT);
+        // (round 5, measured and dropped: staging W_kB on a guess — the option of position 0 — before the states are published, and
+        //  splitting the helper waves so that Z(s) + the list run beside that staging: both shorten the helpers' way to U1 by 3-6k
+        //  cycles in the timing builds and neither moves the end of phase P — profiles/r05_td_kernel_ab_log.txt)
         for (int u = ht; u < BLOCK_ENVS * 2; u += NHT) {                               // Z_d^1 of the entry states, two variables per thread
             const int i = u & (BLOCK_ENVS - 1), h = u / BLOCK_ENVS;
             if (i < nb) {
@@ -776,6 +823,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
         SCG_HSTAMP(14);
+#ifdef SCG_DIAG_SIMD0_FREE      // (diagnostic, correct results) the helper waves that share SIMD 0 with env wave 0 leave U1 to the others
+        if ((wave & 3) != 0)
+#endif
         run_u1_dyn();
 #ifdef SCG_STAMPS
         if (ht == 0 && A.stamps) s_stamp[28] += (unsigned)(__builtin_amdgcn_s_memtime() - stamp_prev);   // helper wave 0: start -> done
@@ -797,7 +847,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     }
 #endif
     if (helpers) { if ((unsigned)(wave - LIST0) < (unsigned)LIST_WAVES) __builtin_amdgcn_s_setprio(SCG_PRIO_LIST); else __builtin_amdgcn_s_setprio(0); }
+    SCG_LITE(2);                                            // this wave's own phase-P work is done
     block_lds_sync();
+    SCG_LITE(3);                                            // ... everybody's
+    SCG_LITEP(7);
 
     SCG_STAMP(0);   // phase P
     // ------------------------------------------------------------------ phase Z (SPEC §3): Z_d^1 of s_next (and of s where no helper did it)
@@ -990,6 +1043,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             if (kBp >= 1) A.cnts[(size_t)b * A.n_vf + kBp] = nupdB;
         }
         SCG_STAMP(pass == 0 ? 1 : 8);    // phase Z (first pass only) + list build + W staging
+        if (pass == 0) SCG_LITE(4);                         // E starts
         // ---- E: Q_v(s_next, .), one 8-item column block per wave-iteration (SPEC §3.1); the tables of a block are built
         // once and serve both value functions. Units [0, npg) are position groups (dense pass), the rest 8-item blocks of
         // the compacted list.
@@ -1089,7 +1143,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         if (MODE != MODE_QVAL && nupd > 0 && !u1_done) run_u1(wave, WAVES, n_units);   // dealt on behind E's blocks
         if (MODE == MODE_QVAL || nupd == 0) continue;
         SCG_STAMP(pass == 0 ? 4 : 11);   // U1 (wave 0's share)
+        if (pass == 0) SCG_LITE(5);                         // this wave's E is done
         block_lds_sync();                                   // s_maxq, s_qsa cross waves; the staging area changes hands
+        if (pass == 0) SCG_LITE(6);                         // ... everybody's: U2 starts
         SCG_STAMP(pass == 0 ? 7 : 14);   // wait for the other waves
 
         // ---- U2: the block partials (SPEC §5). Every action run of A's list is padded with null items to a multiple of 4
@@ -1273,12 +1329,22 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             if (kBp >= 1) A.cnts[(size_t)b * A.n_vf + kBp] = 0;
         }
         SCG_STAMP(15);                // slab stores issued
+        if (pass == 0) SCG_LITE(7);                         // pass 0 done (slab stores issued)
     }
     if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)
         block_lds_sync();
         if (tid == 0 && s_misc[M_FAIL])
             __hip_atomic_fetch_or(A.async_word, SCG_ASYNC_STEP_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#ifdef SCG_STAMPS_LITE
+    if (MODE == MODE_FUSED && A.stamps && lite_role >= 0 && lane == 0) {
+        unsigned long long *o = A.stamps + (size_t)blockIdx.x * STAMP_SLOTS;
+#pragma unroll
+        for (int i = 1; i < 8; ++i) o[lite_role * 8 + i] += lt[i] ? lt[i] - lt[0] : 0ull;
+        o[lite_role * 8] += __builtin_amdgcn_s_memtime() - lt[0];                 // [0]: the wave's whole kernel
+        if (lite_role == 0) { o[32] = lite_r0; o[33] = __builtin_amdgcn_s_memrealtime(); }
+    }
+#endif
 #ifdef SCG_STAMPS
     if (MODE == MODE_FUSED && A.stamps) {
         __syncthreads();

@@ -60,6 +60,15 @@ def allreduce_sum_int(value: int, group, device) -> int:
     return int(t.item())
 
 
+def allreduce_max_int(value: int, group, device) -> int:
+    """Maximum of a host integer over the ranks."""
+    import torch.distributed as dist
+    gloo = dist.get_backend(group) == "gloo"
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if gloo else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def allgather_rows(t: torch.Tensor, group) -> torch.Tensor:
     """Concatenate the rows of `t` ([n_r, ...], n_r differing per rank) over the ranks, in rank order."""
     import torch.distributed as dist

@@ -33,7 +33,8 @@ print(f"# oracle_chain_evidence map {a.map} envs {N} options {K} alpha {a.alpha}
 def make(seed, r_succ, rule):
     orc = sc_oracle.Oracle(m, SCALE, n_envs=N, n_options=K, seed=seed, enabled_mask=0, n_threads=a.threads, gamma=0.99, alpha=a.alpha,
                            epsilon=0.05, r_option_success=r_succ, max_episode_steps=2000, max_option_steps=a.max_option_steps)
-    orc.p.exit_rule = rule
+    orc.p.exit_rule = rule % 10
+    orc.p.select_rule = rule // 10          # (rules >= 10: value-gated entry on top of exit rule rule % 10)
     orc.set_trace(64)
     return orc
 

@@ -112,3 +112,10 @@ def test_async_status_word_decoding(pkg):
     small = C.create_string_buffer(8)
     assert lib.scg_decode_async_word(0x1, small, 8) == -5 and len(small.value) == 7      # truncated, terminated
     assert lib.scg_strerror(-5).startswith(b"an earlier launch")
+
+
+def test_automatic_block_geometry_table(pkg):
+    """SPEC §5 / DESIGN §3.6: the block size a context picks from its env count (no GPU needed for the rule itself)."""
+    f = pkg.auto_block_envs
+    assert [f(n) for n in (1, 4096, 64 * 256, 64 * 256 + 1, 128 * 256, 128 * 256 + 1, 65536, 524288)] == [64, 64, 64, 128, 128, 256, 256, 256]
+    assert all(f(n) in pkg.BLOCK_ENVS_BUILDS for n in range(1, 70000, 997))

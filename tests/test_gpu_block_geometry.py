@@ -63,3 +63,21 @@ def test_contexts_of_different_geometry_live_side_by_side():
             a.step_batch(learn=False)
     for k in ("x", "y", "vx", "vy", "action", "ep_steps", "reward", "done"):
         assert torch.equal(getattr(ags[0].state, k), getattr(ags[1].state, k)), k
+
+
+def test_block_geometry_is_chosen_from_the_env_count(monkeypatch):
+    """block_envs=None (and no SCG_BLOCK_ENVS): the smallest build whose workgroups fit the chip's 256 CUs in one round — a pure
+    function of the env count, so two agents of equal size always agree; an explicit argument or the environment variable wins."""
+    from skill_chaining_with_graphs_amd import SkillChainingAgent
+    monkeypatch.delenv("SCG_BLOCK_ENVS", raising=False)
+    picks = {}
+    for n in (1, 4096, 16384, 16385, 32768, 40000):
+        ags = [SkillChainingAgent("pinball_simple", n, 1, seed=s) for s in (1, 2)]
+        assert ags[0].ctx.block_envs == ags[1].ctx.block_envs
+        picks[n] = ags[0].ctx.block_envs
+        ags[0].step_batch()                                                       # (and the chosen build runs)
+        del ags
+    assert picks == {1: 64, 4096: 64, 16384: 64, 16385: 128, 32768: 128, 40000: 256}
+    assert SkillChainingAgent("pinball_simple", 4096, 0, block_envs=256).ctx.block_envs == 256
+    monkeypatch.setenv("SCG_BLOCK_ENVS", "128")
+    assert SkillChainingAgent("pinball_simple", 4096, 0).ctx.block_envs == 128

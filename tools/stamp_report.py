@@ -21,8 +21,12 @@ lib, ctx = agent.ctx.lib, agent.ctx._ctx
 lib.scg_diag_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 nblk = n // lib.scg_block_envs()
 lib.scg_diag_stamps(ctx, None, 1)
+lib.scg_profile_reset(ctx, 4)                      # HIP event pairs round every 4th fused-kernel launch: the same launches' wall time
 for _ in range(args.steps): agent.step_batch()
 torch.cuda.synchronize()
+ms, cnt = C.c_double(0.0), C.c_int64(0)
+lib.scg_profile_read(ctx, C.byref(ms), C.byref(cnt))
+kernel_us = 1e3 * ms.value / max(cnt.value, 1)
 out = np.zeros((nblk, 48), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
 names = ["phase P (rest: trace, hist, barrier)", "pass 0: phase Z + flags + (W staging)", "P: physics, pooled (env, edge) pair groups + hand-offs", "pass 0: E (eval, both VFs)", "pass 0: U1 (only when no helper ran it)",
@@ -34,6 +38,8 @@ mean = out.astype(np.float64).mean(0) / args.steps
 tot = mean[:32].sum() - mean[28] - mean[29] - mean[30] - mean[10:15].sum()
 print(f"wave-0 cycles per launch (mean over {nblk} blocks), total {tot:.0f} cycles (s_memtime ticks = shader cycles... 100MHz? see below)")
 for nme, v in zip(names, mean): print(f"  {nme:36s} {v:10.0f}  {100*v/tot:5.1f} %")
+print(f"fused kernel by HIP events (this build, {cnt.value} launches): {kernel_us:.2f} us -> wave 0's {tot:.0f} cycles in that time = {tot / kernel_us / 1e3:.3f} GHz "
+      f"(lower bound of the shader clock: the workgroup starts a little after the launch and ends a little before it does)")
 print("E phase per wave (cycles, mean over blocks):", np.round(mean[32:48]).astype(int).tolist())
 per_block = out[:, :32].astype(np.float64).sum(1) / args.steps
 print(f"per-block wave-0 total ticks per launch: min {per_block.min():.0f}  mean {per_block.mean():.0f}  max {per_block.max():.0f}"

@@ -35,3 +35,15 @@ for name in ("pinball_empty", "pinball_simple", "pinball_maze"):
     print(name, m.n_edges, "edges: pinball_step", round(t_ms(step) - t_ms(copies), 4), "ms / 65536 envs")
 W = torch.randn(5 * 1296, device="cuda:0") * 0.01
 print("q_values", round(t_ms(lambda: ctx.q_values((x, y, vx, vy), W)), 4), "ms / 65536 envs")
+# SkillChainingAgent.q_update on explicit transitions (td_kernel<MODE_TRANS> + reduce) and its pieces' context: the fused step's own
+# kernel on the same 65 536 envs, root only (no option work), for scale
+xn, yn, vxn, vyn = x0.clone(), y0.clone(), vx0.clone(), vy0.clone()
+ctx.pinball_step((xn, yn, vxn, vyn), act)
+r = torch.full((N,), -1.0, device="cuda:0"); cont = torch.full((N,), 0.99, device="cuda:0")
+Wall = torch.randn(1 * 5 * 1296, device="cuda:0") * 0.01
+print("q_update (65536 transitions, one value function, apply)", round(1e3 * t_ms(lambda: ctx.q_update(0, (x0, y0, vx0, vy0), act, r, cont, (xn, yn, vxn, vyn), Wall)), 1), "us")
+print("q_update without apply", round(1e3 * t_ms(lambda: ctx.q_update(0, (x0, y0, vx0, vy0), act, r, cont, (xn, yn, vxn, vyn), Wall, apply=False)), 1), "us")
+from skill_chaining_with_graphs_amd import SkillChainingAgent
+ag = SkillChainingAgent("pinball_simple", N, 0, seed=0)
+ag.domain.reset_random(seed=1)
+print("fused step-batch, root only (act + physics + TD + apply)", round(1e3 * t_ms(lambda: ag.step_batch(), 200), 1), "us")
