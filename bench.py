@@ -30,7 +30,7 @@ MAP = "pinball_simple"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32-input MFMA peak (= the FP32 vector peak)
 BYTES_PER_ENV_STEP = 46         # SURVEY.md §8(d) algorithmic HBM bytes per env-step
-HP = dict(gamma=0.99, alpha=1e-3, epsilon=0.05, r_option_success=100.0, max_episode_steps=2000,
+HP = dict(gamma=0.99, alpha=1e-3, epsilon=0.05, r_option_success=0.0, max_episode_steps=2000,
           max_option_steps=250)
 
 
@@ -183,8 +183,8 @@ def extra_measurements(steps, warmup):
                                                   "envs_in_an_option_at_end": int((ag.state.option_id > 0).sum())}
     del ag
     # configs[2] on discovered options
-    hp = dict(HP, alpha=0.02, r_option_success=10000.0)       # a learning rate at which the root reaches the goal within the untimed
-    ag = SkillChainingAgent(MAP, ENVS_PER_GPU, N_OPTIONS, seed=0, **hp)     # warm-up; completion reward of the goal's scale (DESIGN: chain evidence)
+    hp = dict(HP, alpha=0.02, update_count_floor=ENVS_PER_GPU // 16)       # a learning rate at which the root reaches the goal within the untimed
+    ag = SkillChainingAgent(MAP, ENVS_PER_GPU, N_OPTIONS, seed=0, **hp)     # warm-up; small value functions take steps as if they had n_envs / 16 items (SPEC §5 apply: DESIGN §9)
     ag.enable_tracing(64)
     warm = 3000
     for _ in range(warm):
@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--options", type=int, default=N_OPTIONS)
     ap.add_argument("--shared-weights", action="store_true", help="configs[4]: all-reduce dW over RCCL each step")
     ap.add_argument("--ordered-sum", action="store_true", help="with --shared-weights: one all-gather + the sum in rank order "
-                    "inside the apply launch (scg_apply_update_slots: bit-identical weights on any rank count) instead of the all-reduce")
+                    "inside the apply launch (scg_apply_update_slots: identical weights on every rank of the run, reproducible by the oracle for any number of ranks) instead of the all-reduce")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = CPU-side rehearsal of the N>1 path on a 1-GPU box (every rank computes on cuda:0)")
     ap.add_argument("--block-envs", type=int, default=None, choices=[64, 128, 256],

@@ -57,6 +57,11 @@ typedef struct {
     uint64_t seed;
     float gamma, alpha, epsilon, r_option_success;
     int32_t max_episode_steps, max_option_steps;
+    int32_t update_count_floor;   /* SPEC §5 apply: the divisor of a value function's summed update is max(n_k, floor). 0 = plain n_k. A value
+                                   * function with a handful of update items otherwise takes full-size steps on their average and runs away
+                                   * (profiles/r05_oracle_chain_curves_gated.txt: NaN weights in an option few envs run); n_envs / 16 is a safe choice */
+    int32_t reoffer_period;       /* SPEC §4.2: an env that stays out of option k although inside its initiation set (option_id = -k) is offered k
+                                   * again when (t + global env id) % reoffer_period == 0. A power of two; 1 (or 0) = every step */
 } scg_config;
 
 /* flags for scg_step */
@@ -74,7 +79,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg);
 int scg_destroy(scg_ctx *ctx);
 /* change hyper-parameters between steps (n_envs / n_options / device are fixed at create) */
 int scg_set_hparams(scg_ctx *ctx, float gamma, float alpha, float epsilon, float r_option_success,
-                    int32_t max_episode_steps, int32_t max_option_steps);
+                    int32_t max_episode_steps, int32_t max_option_steps, int32_t update_count_floor, int32_t reoffer_period);
 
 /* SPEC §1.1. All HOST pointers, copied. edges[n_edges][8], starts[n_starts][2], scale[1296].
  * map_scalars = {R, hstep, R2, TX, TY, TR2}. */
@@ -109,7 +114,7 @@ int scg_apply_update_packed(scg_ctx *ctx, float *W, const float *G_packed, void 
 /* The ORDER-PINNED multi-rank sum (ABI 3): `slots` holds the packed operands of n_slots ranks, slot r at
  * slots + r * slot_stride floats (slot_stride >= n_vf*6480 + n_vf) — what an all-gather of every rank's G_packed leaves —
  * and the update is applied from their sum taken IN SLOT ORDER, ((G_0 + G_1) + G_2) + ..., element by element
- * (SPEC §5): every rank then holds bit-identical weights whatever the rank count, and the CPU oracle reproduces them.
+ * (SPEC §5): the weights are then identical on every rank of a run and reproducible by the oracle for any number of ranks (the rank count, like the block size and the seed, is part of the run's identity).
  * (An all-reduce's order of additions is the library's business: exact for two ranks, to rounding beyond.) */
 int scg_apply_update_slots(scg_ctx *ctx, float *W, const float *slots, int32_t n_slots, int64_t slot_stride, void *stream);
 
@@ -177,7 +182,9 @@ int scg_collect_examples(scg_ctx *ctx, uint32_t event_bits, uint8_t *prev_in, in
  * the same), and a matching scg_collect_examples right after it needs one launch instead of two. Results are identical either
  * way; a call that does not match the announcement, or comes without a step in between, takes the two-launch path.
  * event_bits = 0 withdraws the announcement. prev_in and count are READ by every following scg_step until then (device
- * pointers kept in the ctx): keep them alive, or withdraw the announcement before freeing them. */
+ * pointers kept in the ctx): keep them alive, or withdraw the announcement before freeing them. scg_step checks them best-effort
+ * (hipPointerGetAttributes: memory handed back to the DRIVER is noticed and refused with SCG_ERR_STATE; memory a caching allocator
+ * such as torch's has merely recycled still reads as a device allocation and is NOT noticed) — the rule above is the contract. */
 int scg_arm_collect(scg_ctx *ctx, uint32_t event_bits, const uint8_t *prev_in, int32_t l_pos, int32_t l_neg, const int32_t *count);
 
 /* Gestation (SPEC §4.4; Konidaris & Barto 2009: a new option learns off-policy before it may run). Bit k of gest_mask:

@@ -353,7 +353,7 @@ int sco_q_update_grad(const sco_params *p, int n, const float *s4[4], const uint
 void sco_apply(const sco_params *p, int n_vf, float *W, const float *G, const int32_t *n_k) {
     for (int k = 0; k < n_vf; ++k) {
         if (n_k[k] <= 0) continue;
-        float step = p->alpha / (float)n_k[k];
+        float step = p->alpha / (float)(n_k[k] > p->nk_floor ? n_k[k] : p->nk_floor);
         for (int a = 0; a < NACT; ++a)
             for (int f = 0; f < NF; ++f) {
                 size_t i = ((size_t)k * NACT + a) * NF + f;
@@ -369,41 +369,35 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
     const int N = p->n_envs;
     const int n_vf = p->n_options + 1;
     const int nblk = (N + g_block_envs - 1) / g_block_envs;
-    /* SPEC §5: envs are taken in the order of (option_id at entry, env index) — a stable counting sort —
-     * and blocks are 128 consecutive positions of that order. Every per-env array stays indexed by env. */
+    /* SPEC §5: envs are taken in the order of (sort key at entry, env index) — a stable counting sort. The key comes from the
+     * signed option id: k in [1, n_vf) -> k (running option k); 0 and -k (no option in sight / inside option k's initiation set
+     * but staying out of it, §4.2: either way the env runs the root) -> 0; anything else -> the last key n_vf. */
     int *perm = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
     {
-        /* SPEC §5 env order. Key of an env: its option id, ids outside [0, n_vf) -> n_vf (never produced by the
-         * step). Runs of the keys 1..6 in key order, envs in env order inside a run; envs of key 0 (running no
-         * option), in env order, are the filler. */
-        int tot[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int e = 0; e < N; ++e) {
-            int o = option_id[e];
-            if (o < 0 || o >= n_vf) o = n_vf;
-            tot[o]++;
-        }
+        enum { NK = 7 };
+        int tot[NK];
+        for (int k = 0; k < NK; ++k) tot[k] = 0;
+#define SCO_KEY(o) ((o) <= 0 ? ((o) > -n_vf ? 0 : n_vf) : ((o) < n_vf ? (o) : n_vf))
+        for (int e = 0; e < N; ++e) tot[SCO_KEY(option_id[e])]++;
         /* lists of envs per key, env order */
-        int *lst[7], fillpos = 0;
-        for (int k = 0; k < 7; ++k) lst[k] = (int *)malloc(sizeof(int) * (size_t)(tot[k] > 0 ? tot[k] : 1));
+        int *lst[NK], fillpos = 0;
+        for (int k = 0; k < NK; ++k) lst[k] = (int *)malloc(sizeof(int) * (size_t)(tot[k] > 0 ? tot[k] : 1));
         {
-            int cnt7[7] = {0, 0, 0, 0, 0, 0, 0};
-            for (int e = 0; e < N; ++e) {
-                int o = option_id[e];
-                if (o < 0 || o >= n_vf) o = n_vf;
-                lst[o][cnt7[o]++] = e;
-            }
+            int cntk[NK];
+            for (int k = 0; k < NK; ++k) cntk[k] = 0;
+            for (int e = 0; e < N; ++e) { int k = SCO_KEY(option_id[e]); lst[k][cntk[k]++] = e; }
         }
         int S = 0, Rn = 0;
-        for (int k = 1; k < 7; ++k) { S += tot[k]; Rn += tot[k] > 0; }
+        for (int k = 1; k < NK; ++k) { S += tot[k]; Rn += tot[k] > 0; }
         const int B = g_block_envs, Bf = N / B;
         int c = B;
         if (Bf > Rn && S > 0) { c = (S + (Bf - Rn) - 1) / (Bf - Rn); if (c > B) c = B; }
         int U = 0;
-        for (int k = 1; k < 7; ++k) U += (tot[k] + c - 1) / c;
+        for (int k = 1; k < NK; ++k) U += (tot[k] + c - 1) / c;
         int pos = 0;
         if ((long)U * B <= N) {
             /* chunked layout: every block takes at most c envs of one run, key-0 envs fill it up */
-            for (int k = 1; k < 7; ++k)
+            for (int k = 1; k < NK; ++k)
                 for (int r = 0; r < tot[k]; r += c) {
                     const int m = tot[k] - r < c ? tot[k] - r : c;
                     for (int i = 0; i < m; ++i) perm[pos++] = lst[k][r + i];
@@ -411,14 +405,15 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 }
         } else {
             /* padded layout: runs back to back, each padded to the next block boundary while key-0 envs are left */
-            for (int k = 1; k < 7; ++k) {
+            for (int k = 1; k < NK; ++k) {
                 for (int r = 0; r < tot[k]; ++r) perm[pos++] = lst[k][r];
                 if (tot[k] > 0)
                     while (pos % B != 0 && fillpos < tot[0]) perm[pos++] = lst[0][fillpos++];
             }
         }
         while (fillpos < tot[0]) perm[pos++] = lst[0][fillpos++];
-        for (int k = 0; k < 7; ++k) free(lst[k]);
+        for (int k = 0; k < NK; ++k) free(lst[k]);
+#undef SCO_KEY
     }
     float *P = (float *)malloc(sizeof(float) * (size_t)(nblk > 0 ? nblk : 1) * n_vf * NACT * NF);
     int *cnts = (int *)calloc((size_t)(nblk > 0 ? nblk : 1) * n_vf, sizeof(int));
@@ -474,7 +469,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                 nx = p->starts[2 * si]; ny = p->starts[2 * si + 1]; nvx = 0.0f; nvy = 0.0f;
             }
             rec[i].sn[0] = nx; rec[i].sn[1] = ny; rec[i].sn[2] = nvx; rec[i].sn[3] = nvy;
-            int o = option_id[e];
+            int o = option_id[e] > 0 ? option_id[e] : 0;        /* (-k: inside option k's initiation set, staying with the root) */
             int keep = 0;
             ro[i] = 0.0f; co[i] = 0.0f; xo[i] = 0; xg[i] = 0; rootmax[i] = 0.0f;
             if (o >= 1) {
@@ -497,8 +492,12 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
                     if (p->parents[k] != 0 && in_set(p, clf, p->parents[k], nx, ny)) continue;
                     on = k; break;
                 }
-            o_t[i] = o; o_n[i] = on;
-            entering[i] = p->select_rule == 1 && !keep && on >= 1; candmax[i] = 0.0f;
+            int was_declined = (dn == 0 && option_id[e] < 0) ? -option_id[e] : 0;   /* SPEC §4.2: the option this env stays out of although inside its initiation set (a new episode is a new visit) */
+            /* SPEC §4.2: an env that stays out of option k is offered k again only every reoffer_period-th step (staggered by env id) */
+            int sticky = p->select_rule == 1 && !keep && on >= 1 && on == was_declined && p->reoffer_period > 1 &&
+                         ((t + g) % (uint64_t)p->reoffer_period) != 0;
+            o_t[i] = o; o_n[i] = sticky ? 0 : on;
+            entering[i] = p->select_rule == 1 && !keep && on >= 1 && !sticky; candmax[i] = 0.0f;
             r0[i] = rew; c0[i] = dn ? 0.0f : p->gamma;
             /* SPEC §4.4: gestating options that hold the ENTRY state in their initiation set learn off-policy from this
              * transition, as if the env had been running them (no time-out); their successes are counted */
@@ -532,7 +531,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
             /* outputs */
             action[e] = (uint8_t)a; reward[e] = rew; done[e] = (uint8_t)dn;
             x[e] = nx; y[e] = ny; vx[e] = nvx; vy[e] = nvy;
-            option_id[e] = on;
+            option_id[e] = sticky ? -on : on;
             opt_steps[e] = keep ? opt_steps[e] + 1 : 0;
             ep_steps[e] = dn ? 0 : eps1;
             state_tables(rec[i].s[0], rec[i].s[1], rec[i].s[2], rec[i].s[3], tab_s[i].AB, tab_s[i].CD);
@@ -569,7 +568,7 @@ void sco_step(const sco_params *p, float *x, float *y, float *vx, float *vy, int
         for (int i = 0; i < nb; ++i) {
             if (!entering[i] || candmax[i] >= rootmax[i]) continue;
             int e = env_of[i];
-            option_id[e] = 0;
+            option_id[e] = -o_n[i];
             for (int a = 0; a < NACT; ++a) qcache[(size_t)a * N + e] = rootq[i][a];
         }
         free(tab_s); free(tab_n); free(items);

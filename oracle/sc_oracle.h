@@ -54,6 +54,11 @@ typedef struct {
     int32_t exit_rule;
     /* SPEC §4.2 option selection: 0 = forced (an env inside an initiation set must run the option); 1 = value-gated entry */
     int32_t select_rule;
+    /* SPEC §5 apply: the divisor of a value function's summed update is max(n_k, nk_floor) (0 = plain n_k) */
+    int32_t nk_floor;
+    /* SPEC §4.2: an env staying out of option k (option_id = -k) is offered k again when (t + global env id) % reoffer_period == 0
+     * (<= 1: every step) */
+    int32_t reoffer_period;
 } sco_params;
 
 void sco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("ring_len", C.c_int32),
         ("parents", C.c_int32 * 8),
         ("gest_mask", C.c_uint32), ("gest_succ", C.c_void_p),
-        ("exit_rule", C.c_int32), ("select_rule", C.c_int32),
+        ("exit_rule", C.c_int32), ("select_rule", C.c_int32), ("nk_floor", C.c_int32), ("reoffer_period", C.c_int32),
     ]
 
 
@@ -93,8 +93,8 @@ class Oracle:
     """Holds the map tables + hyper-parameters; methods mirror the C-ABI entry points on numpy arrays."""
 
     def __init__(self, pmap, scale, n_envs=1, n_options=0, seed=0, env_id_base=0, gamma=0.99, alpha=1e-3,
-                 epsilon=0.05, r_option_success=100.0, max_episode_steps=10000, max_option_steps=250,
-                 enabled_mask=0, n_threads=1):
+                 epsilon=0.05, r_option_success=0.0, max_episode_steps=10000, max_option_steps=250,
+                 enabled_mask=0, n_threads=1, update_count_floor=0, reoffer_period=4):
         self.L = lib()
         self.edges = _f32(pmap.edges)
         self.starts = _f32(pmap.starts)
@@ -108,6 +108,9 @@ class Oracle:
                         edges=self.edges.ctypes.data, starts=self.starts.ctypes.data,
                         radius=sc[0], hstep=sc[1], r2=sc[2], tx=sc[3], ty=sc[4], tr2=sc[5],
                         scale=self.scale.ctypes.data)
+        self.p.nk_floor = update_count_floor
+        self.p.reoffer_period = reoffer_period
+        self.p.exit_rule, self.p.select_rule = 2, 1            # SPEC §4.2 (other values: experiments of tests/oracle_chain_evidence.py)
         self.n_vf = n_options + 1
         self.set_parents(list(range(-1, 7)))            # default chain: 1 -> goal, k -> k-1
 

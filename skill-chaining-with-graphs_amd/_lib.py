@@ -40,6 +40,8 @@ class ScgConfig(C.Structure):
         ("r_option_success", C.c_float),
         ("max_episode_steps", C.c_int32),
         ("max_option_steps", C.c_int32),
+        ("update_count_floor", C.c_int32),
+        ("reoffer_period", C.c_int32),
     ]
 
 
@@ -51,7 +53,7 @@ _SIGS = {
     "scg_last_error": (C.c_char_p, [_P]),
     "scg_create": (C.c_int, [C.POINTER(_P), C.POINTER(ScgConfig)]),
     "scg_destroy": (C.c_int, [_P]),
-    "scg_set_hparams": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32]),
+    "scg_set_hparams": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "scg_set_map": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P]),
     "scg_step": (C.c_int, [_P] + [_P] * 13 + [C.c_uint32, C.c_uint64, C.c_uint32, _P]),
     "scg_grad_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
@@ -113,12 +115,14 @@ def lib_path(block_envs: int | None = None) -> str:
     return os.path.join(_HERE, "csrc", f"libscg_hip_b{block_envs}.so")
 
 
-def load(block_envs: int | None = None) -> C.CDLL:
-    """Load the HIP library of a block geometry (once each). Raises ScgError loudly when it has not been built."""
-    key = BLOCK_ENVS_DEFAULT if block_envs is None else int(block_envs)
+def load(block_envs: int | None = None, path: str | None = None) -> C.CDLL:
+    """Load the HIP library of a block geometry (once each). Raises ScgError loudly when it has not been built.
+    `path`: a variant build of the same ABI (timing / fault-injection builds of csrc/Makefile) instead of the geometry's library."""
+    key = (BLOCK_ENVS_DEFAULT if block_envs is None else int(block_envs)) if path is None else os.path.abspath(path)
     if key in _libs:
         return _libs[key]
-    path = lib_path(key)
+    if path is None:
+        path = lib_path(key)
     if not os.path.exists(path):
         raise ScgError(
             f"{path} is missing: the HIP extension has not been built "
@@ -140,7 +144,7 @@ def load(block_envs: int | None = None) -> C.CDLL:
             raise ScgError(f"{path} does not export {name} although it reports ABI version {ver}: rebuild it") from None
         fn.restype = res
         fn.argtypes = args
-    if block_envs is not None and int(lib.scg_block_envs()) != key:
+    if block_envs is not None and isinstance(key, int) and int(lib.scg_block_envs()) != key:
         raise ScgError(f"{path} is built for {int(lib.scg_block_envs())}-env blocks, not {key}: rebuild it")
     _libs[key] = lib
     return lib

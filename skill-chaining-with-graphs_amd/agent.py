@@ -38,8 +38,8 @@ class SkillChainingAgent:
         self._gest_need = {}
         self.t = 0
         self.group = group            # torch.distributed group for shared option-Q weights (or None)
-        self.ordered_sum = bool(ordered_sum)   # shared weights summed in rank order from an all-gather (bit-identical on any
-        self._slots = None                     # rank count, reproduced by the oracle) instead of an all-reduce (exact for two ranks)
+        self.ordered_sum = bool(ordered_sum)   # shared weights summed in rank order from an all-gather (identical on every
+        self._slots = None                     # rank of the run, reproduced by the oracle) instead of an all-reduce (exact for two ranks)
         self.allreduce_timing = None  # see time_allreduce()
         self.domain = PinballDomain(self.ctx)
         self.state: EnvState = self.domain.state

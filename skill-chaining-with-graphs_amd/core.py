@@ -33,20 +33,23 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
 
 
 class ScgContext:
-    # r_option_success defaults to the task goal's 10 000: a completion reward that is small against the step costs an option
-    # pays on its way (-1 / -5 per step) makes LEAVING the initiation set at once (termination is worth 0) the option's best
-    # policy, and the chain then hurts (profiles/r04_chain_evidence_rsucc50.txt against _rsucc10000.txt)
+    # r_option_success defaults to 0: with SPEC §4.2's value-gated entry an option is entered where its value function promises at
+    # least the root's, and both estimate the TASK's return (an option that ends bootstraps from the root) — a completion bonus
+    # inflates the option's side of that comparison (profiles/r05_oracle_chain_curves_*.txt: 10 000 collapses a seed, 0 is best)
     def __init__(self, n_envs: int, n_options: int, pmap: PinballMap, *, device: int = 0, seed: int = 0,
                  env_id_base: int = 0, gamma: float = 0.99, alpha: float = 1e-3, epsilon: float = 0.05,
-                 r_option_success: float = 10000.0, max_episode_steps: int = 10000,
-                 max_option_steps: int = 250, block_envs: Optional[int] = None):
+                 r_option_success: float = 0.0, max_episode_steps: int = 10000,
+                 max_option_steps: int = 250, update_count_floor: int = 0, reoffer_period: int = 4,
+                 block_envs: Optional[int] = None,
+                 library: Optional[str] = None):
         if not torch.cuda.is_available():
             raise ScgError("no GPU visible to torch: the HIP path cannot run and there is no CPU fallback")
         if not (0 <= n_options <= MAX_OPTIONS):
             raise ScgError(f"n_options must be in [0, {MAX_OPTIONS}]")
         if block_envs is None:                               # SPEC §5 geometry: SCG_BLOCK_ENVS pins it, else by the env count
             block_envs = int(os.environ["SCG_BLOCK_ENVS"]) if os.environ.get("SCG_BLOCK_ENVS") else _lib.auto_block_envs(n_envs)
-        self.lib = _lib.load(block_envs)                     # one library per geometry (64 / 128 / 256 envs per block = per workgroup)
+        # one library per geometry (64 / 128 / 256 envs per block = per workgroup); `library`: a variant build of the same ABI
+        self.lib = _lib.load(block_envs) if library is None else _lib.load(None, path=library)
         self.block_envs = int(self.lib.scg_block_envs())
         self.n_envs, self.n_options, self.n_vf = int(n_envs), int(n_options), int(n_options) + 1
         self.device = torch.device("cuda", device)
@@ -54,7 +57,8 @@ class ScgContext:
         self.cfg = ScgConfig(n_envs=n_envs, n_options=n_options, fourier_order=_lib.FOURIER_ORDER,
                              device=device, env_id_base=env_id_base, seed=seed, gamma=gamma, alpha=alpha,
                              epsilon=epsilon, r_option_success=r_option_success,
-                             max_episode_steps=max_episode_steps, max_option_steps=max_option_steps)
+                             max_episode_steps=max_episode_steps, max_option_steps=max_option_steps,
+                             update_count_floor=update_count_floor, reoffer_period=reoffer_period)
         self._ctx = C.c_void_p()
         _lib.check(self.lib.scg_create(C.byref(self._ctx), C.byref(self.cfg)), None, "scg_create")
         self.scale = fourier_scale_table()
@@ -98,7 +102,7 @@ class ScgContext:
             setattr(self.cfg, k, v)
         c = self.cfg
         self._call("scg_set_hparams", c.gamma, c.alpha, c.epsilon, c.r_option_success,
-                   c.max_episode_steps, c.max_option_steps)
+                   c.max_episode_steps, c.max_option_steps, c.update_count_floor, c.reoffer_period)
 
     # ------------------------------------------------------------------ fused step-batch
     def _step_flags(self, learn: bool, apply: bool) -> int:
@@ -260,8 +264,7 @@ class ScgContext:
 
     def apply_update_slots(self, W: torch.Tensor, slots: torch.Tensor) -> None:
         """The order-pinned multi-rank update (SPEC §5): `slots` [n_ranks, n_vf*5*1296 + n_vf] holds every rank's packed operand
-        (an all-gather of grad_packed()); G and the counts are summed in slot order, so all ranks hold bit-identical weights
-        whatever their number."""
+        (an all-gather of grad_packed()); G and the counts are summed in slot order: the weights are identical on every rank of a run and reproducible by the oracle for any number of ranks (the rank count, like the block size and the seed, is part of the run's identity)."""
         per = self.n_vf * NUM_ACTIONS * NUM_FEATURES + self.n_vf
         if slots.dim() != 2 or slots.shape[1] != per or not slots.is_contiguous():
             raise ScgError(f"slots must be a contiguous [n_ranks, {per}] tensor")

@@ -45,7 +45,8 @@ struct StepArgs {
     // env state (FUSED: in/out; TRANS/QVAL: in)
     float *x, *y, *vx, *vy;
     int32_t *option_id, *opt_steps, *ep_steps;
-    int32_t *hist_next;        // [rows of 256 envs][8] counts of the option ids this step leaves (null = off)
+    int32_t *hist_next;        // [rows of 256 envs][HSTRIDE] counts of the SORT KEYS (sort_key) this step leaves (null = off)
+    float4 *qalt;              // FUSED: [positions][2] SPEC §4.2: the root's Q(s', .) of an env about to enter an option (read by commit_row if the env is declined)
     float4 *outrec;            // FUSED: [positions][OREC] per-env results in env-ORDER position (one 64-byte line:
                                // state', {reward, bits, counters}, Q(s', .) of the VF acting next), committed to the
                                // caller's arrays by commit_row (coalesced) instead of 4-byte scatters from here
@@ -69,6 +70,7 @@ struct StepArgs {
     int32_t *cnts;                 // [nblk][n_vf]
     unsigned long long *stamps;    // diagnostic build only
     uint32_t *async_word;          // host-visible sticky status word (a hand-off poll that runs out is reported there)
+    int32_t *fail_flag;            // ... and its device-side twin: the reduce launch of the same step reads it (no apply, no commit)
     int32_t n, n_vf, k_lo, k_hi;
     uint32_t enabled, learn;       // learn: 1 = learning step
     uint32_t gest;                 // SPEC §4.4: options in gestation (classifier known, not selectable, learning off-policy)
@@ -78,6 +80,7 @@ struct StepArgs {
     int64_t env_base;
     float gamma, epsilon, r_succ;
     int32_t max_ep, max_opt;
+    uint32_t reoffer_mask;         // SPEC §4.2: reoffer_period - 1 (0: an option is offered every step)
     MapScalars ms;
 };
 
@@ -160,6 +163,7 @@ struct ReduceArgs {
     int32_t nblk, n_vf;
     float alpha;
     uint32_t apply;
+    int32_t nk_floor;              // SPEC §5 apply: divisor max(n_k, nk_floor)
     // next step's env order (SPEC §5) as extra workgroups (option_id null = off): the fused kernel has counted
     // the new option ids per row of 256 envs into `hist`; `hist_zero` is the other buffer, cleared for the next step
     const int32_t *option_id;
@@ -168,12 +172,14 @@ struct ReduceArgs {
     // commit of the fused kernel's per-position results to the caller's arrays (outrec null = off), one row of
     // 256 envs per wave; with `sort` the same wave then places its row in the next env order
     const float4 *outrec;
+    const float4 *qalt;            // the root's Q(s', .) of the envs whose result line carries the declined mark (SPEC §4.2)
     int32_t *invperm;              // [n] position of env e in the current order (in: this step's, out: the next's)
     float *x, *y, *vx, *vy, *reward;
     int32_t *option_id_out, *opt_steps, *ep_steps;
     uint8_t *action, *done;
     float *qcache;                 // [5][n], null = the step ran no TD pass (diagnostic): leave it alone
     int32_t sort;
+    const int32_t *fail_flag;      // set by a workgroup of the step kernel that gave up: the step is void (no apply, no commit)
     // an announced example trigger (scg_arm_collect; c_rows null = none): the commit rows leave what collect_count_kernel would
     const uint8_t *c_events, *c_prev;
     const int32_t *c_evlen, *c_count;
@@ -209,17 +215,25 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xFFFFFFFFu /
 __device__ __forceinline__ int div_by(int r, int d, uint32_t m) { return d == 1 ? r : (int)__umulhi((uint32_t)r, m); }
 __device__ __forceinline__ int collect_v(int e, int n, const uint8_t *events, const uint8_t *prev_in, uint32_t bits,
                                          const int32_t *ev_len, int ring_len, int L, bool &in_out);
+// SPEC §5 sort key of an env from its signed option id: k in [1, n_vf) (running option k) -> k; 0 and -k (no option in sight / inside
+// option k's initiation set but staying out of it, §4.2: either way the env runs the root) -> 0; anything else -> the last key n_vf.
+// NKEY keys, count tables with HSTRIDE ints per row.
+constexpr int NKEY = 7, HSTRIDE = 8;
+__device__ __forceinline__ int sort_key(int o, int n_vf) {
+    if (o <= 0) return o > -n_vf ? 0 : n_vf;
+    return o < n_vf ? o : n_vf;
+}
 struct OrderLayout {
     int chunked, c, g, U, Ftot;
     uint32_t mc, mg;               // ceil(2^32 / c), ceil(2^32 / g): exact division of ranks (< 2^24) by mul-high
-    int start[7];                  // position of run k's first env
-    int cnt[7], n[7], F[7];        // chunked: workgroups of run k, its size, key-0 fill slots before it
-    int pad_lo[7], pad_n[7], pad_pos[7], tail_lo, tail_pos;     // padded layout
+    int start[NKEY];               // position of run k's first env
+    int cnt[NKEY], n[NKEY], F[NKEY];   // chunked: workgroups of run k, its size, key-0 fill slots before it
+    int pad_lo[NKEY], pad_n[NKEY], pad_pos[NKEY], tail_lo, tail_pos;     // padded layout
 };
-__device__ __forceinline__ void order_layout(const int tot[7], int n_envs, OrderLayout &L) {
+__device__ __forceinline__ void order_layout(const int tot[NKEY], int n_envs, OrderLayout &L) {
     int S = 0, Rn = 0;
 #pragma unroll
-    for (int k = 1; k < 7; ++k) { S += tot[k]; Rn += tot[k] > 0 ? 1 : 0; L.n[k] = tot[k]; }
+    for (int k = 1; k < NKEY; ++k) { S += tot[k]; Rn += tot[k] > 0 ? 1 : 0; L.n[k] = tot[k]; }
     L.n[0] = tot[0];
     const int Bf = n_envs / BLOCK_ENVS;
     int c = BLOCK_ENVS;
@@ -229,7 +243,7 @@ __device__ __forceinline__ void order_layout(const int tot[7], int n_envs, Order
     L.mc = div_magic((uint32_t)c);
     L.mg = div_magic((uint32_t)max(BLOCK_ENVS - c, 1));
 #pragma unroll
-    for (int k = 1; k < 7; ++k) {
+    for (int k = 1; k < NKEY; ++k) {
         L.cnt[k] = div_by(tot[k] + c - 1, c, L.mc);
         L.start[k] = U * BLOCK_ENVS; L.F[k] = F;
         U += L.cnt[k]; F += L.cnt[k] * BLOCK_ENVS - tot[k];
@@ -242,7 +256,7 @@ __device__ __forceinline__ void order_layout(const int tot[7], int n_envs, Order
         L.mc = div_magic(1u << 30);
         L.pad_lo[0] = 0; L.pad_n[0] = 0; L.pad_pos[0] = 0;
 #pragma unroll
-        for (int k = 1; k < 7; ++k) {
+        for (int k = 1; k < NKEY; ++k) {
             L.start[k] = P; P += tot[k];
             const int need = tot[k] > 0 ? (BLOCK_ENVS - P % BLOCK_ENVS) % BLOCK_ENVS : 0;
             const int pad = min(need, tot[0] - used);
@@ -260,7 +274,7 @@ __device__ __forceinline__ int order_pos0(const OrderLayout &L, int r) {       /
     if (!L.chunked) {
         int pos = L.tail_pos + (r - L.tail_lo);
 #pragma unroll
-        for (int k = 1; k < 7; ++k)
+        for (int k = 1; k < NKEY; ++k)
             if (r >= L.pad_lo[k] && r < L.pad_lo[k] + L.pad_n[k]) pos = L.pad_pos[k] + (r - L.pad_lo[k]);
         return pos;
     }
@@ -268,7 +282,7 @@ __device__ __forceinline__ int order_pos0(const OrderLayout &L, int r) {       /
     int st = 0, cn = 0, nk = 0, f0 = 0;
     bool in_run = false;
 #pragma unroll
-    for (int k = 1; k < 7; ++k) {
+    for (int k = 1; k < NKEY; ++k) {
         const int fills = L.cnt[k] * BLOCK_ENVS - L.n[k];
         if (r >= L.F[k] && r < L.F[k] + fills) { in_run = true; st = L.start[k]; cn = L.cnt[k]; nk = L.n[k]; f0 = L.F[k]; }
     }
@@ -296,19 +310,20 @@ __device__ __forceinline__ int order_pos0(const OrderLayout &L, int r) {       /
 // Load order matters: position first, then the count table, then the record, so that the table's latency hides
 // under the record's and the prefix sums run while the record is in flight. One wave per row (four envs per lane)
 // took 8.3 us of dependent work after the launch floor; see DESIGN §10.
-__device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int row, int wv, int lane, int (*s_x)[24]) {
+__device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int row, int wv, int lane, int (*s_x)[40]) {
+    if (R.fail_flag && *R.fail_flag) return;            // (uniform) a workgroup of this step gave up: the caller's arrays keep the previous step's results
     const bool act = wv < 4 && row < R.nrow;
     const int e = row * 256 + wv * 64 + lane;
     const bool ok = act && e < R.n;
     const int pos_old = ok ? R.invperm[e] : 0;
-    int tot[7], pre[7];
+    int tot[NKEY], pre[NKEY];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) { tot[k] = 0; pre[k] = 0; }
+    for (int k = 0; k < NKEY; ++k) { tot[k] = 0; pre[k] = 0; }
     if (act && R.sort) {
         for (int r = wv * 64 + lane; r < R.nrow; r += 256) {       // this wave's quarter of the count table
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int h = R.hist[r * 8 + k];
+            for (int k = 0; k < NKEY; ++k) {
+                const int h = R.hist[r * HSTRIDE + k];
                 tot[k] += h;
                 if (r < row) pre[k] += h;
             }
@@ -318,24 +333,33 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
     float q4 = 0.0f;
     if (ok) {
         const float4 *r = R.outrec + (size_t)pos_old * OREC;
-        ra = r[0]; rb = r[1]; rq = r[2]; q4 = r[3].x;
+        const float4 r3 = r[3];
+        ra = r[0]; rb = r[1]; rq = r[2]; q4 = r3.x;
+        if (__float_as_uint(r3.y) == OREC_DECLINED) {       // SPEC §4.2: the option promised less than the root — the env stays with the root
+            rq = R.qalt[(size_t)pos_old * 2]; q4 = R.qalt[(size_t)pos_old * 2 + 1].x;
+            rb.y = __uint_as_float(__float_as_uint(rb.y) | 0x01000000u);      // declined: bit 24 of the record's bits
+        }
     }
     int key = -1;
-    uint64_t km[7];
+    uint64_t km[NKEY];
     if (act) {
         if (R.sort) {
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {                   // integer sums: any order
+            for (int k = 0; k < NKEY; ++k) {                   // integer sums: any order
 #pragma unroll
                 for (int m = 1; m < 64; m <<= 1) { tot[k] += __shfl_xor(tot[k], m, 64); pre[k] += __shfl_xor(pre[k], m, 64); }
             }
         }
         const unsigned bits = __float_as_uint(rb.y);
         if (ok) {
-            key = (int)((bits >> 16) & 255u);
+            const int on = (int)((bits >> 16) & 255u);
+            const bool declined = (bits >> 24) & 1u;            // set above from the result line's mark (SPEC §4.2): declined in this step
+            // the caller sees -k: inside option k's initiation set, staying out of it (bits 28..30: it has been since an earlier step)
+            const int oid = declined ? -on : (on ? on : -(int)((bits >> 28) & 7u));
+            key = sort_key(oid, R.n_vf);
             R.x[e] = ra.x; R.y[e] = ra.y; R.vx[e] = ra.z; R.vy[e] = ra.w;
             R.reward[e] = rb.x; R.action[e] = (uint8_t)(bits & 255u); R.done[e] = (uint8_t)((bits >> 8) & 255u);
-            R.option_id_out[e] = key; R.opt_steps[e] = __float_as_int(rb.z); R.ep_steps[e] = __float_as_int(rb.w);
+            R.option_id_out[e] = oid; R.opt_steps[e] = __float_as_int(rb.z); R.ep_steps[e] = __float_as_int(rb.w);
             if (R.qcache) {
                 const size_t n = (size_t)R.n;
                 R.qcache[e] = rq.x; R.qcache[n + e] = rq.y; R.qcache[2 * n + e] = rq.z;
@@ -344,14 +368,14 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
         }
         if (R.sort) {
 #pragma unroll
-            for (int k = 0; k < 7; ++k) km[k] = __ballot(key == k);
-            if (lane < 21) {                                // [0..6] table totals, [7..13] rows before this one, [14..20] this wave's keys
+            for (int k = 0; k < NKEY; ++k) km[k] = __ballot(key == k);
+            if (lane < 3 * NKEY) {                          // [0..NKEY) table totals, [NKEY..2 NKEY) rows before this one, [2 NKEY..3 NKEY) this wave's keys
                 int v = 0;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
+                for (int k = 0; k < NKEY; ++k) {
                     if (lane == k) v = tot[k];
-                    if (lane == 7 + k) v = pre[k];
-                    if (lane == 14 + k) v = __popcll(km[k]);
+                    if (lane == NKEY + k) v = pre[k];
+                    if (lane == 2 * NKEY + k) v = __popcll(km[k]);
                 }
                 s_x[wv][lane] = v;
             }
@@ -362,34 +386,34 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
         int v = collect_v(e, R.n, R.c_events, R.c_prev, R.c_bits, R.c_evlen, R.c_ring_len, R.c_L, in);
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-        if (lane == 0) s_x[wv][21] = v;
+        if (lane == 0) s_x[wv][3 * NKEY] = v;
     }
     if (!R.sort && !R.c_rows) return;                       // workgroup-uniform
     __syncthreads();
     if (R.c_rows && wv == 0 && lane == 0 && row < R.nrow) {
-        R.c_rows[row] = s_x[0][21] + s_x[1][21] + s_x[2][21] + s_x[3][21];
+        R.c_rows[row] = s_x[0][3 * NKEY] + s_x[1][3 * NKEY] + s_x[2][3 * NKEY] + s_x[3][3 * NKEY];
         if (row == 0) R.c_rows[R.nrow] = *R.c_count;        // the buffer's fill level
     }
     if (!R.sort || !act) return;
-    int off[7];
+    int off[NKEY];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NKEY; ++k) {
         tot[k] = s_x[0][k] + s_x[1][k] + s_x[2][k] + s_x[3][k];
-        off[k] = s_x[0][7 + k] + s_x[1][7 + k] + s_x[2][7 + k] + s_x[3][7 + k];
+        off[k] = s_x[0][NKEY + k] + s_x[1][NKEY + k] + s_x[2][NKEY + k] + s_x[3][NKEY + k];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) off[k] += w < wv ? s_x[w][14 + k] : 0;      // rank of this wave's first key-k env within its run
+        for (int w = 0; w < 3; ++w) off[k] += w < wv ? s_x[w][2 * NKEY + k] : 0;      // rank of this wave's first key-k env within its run
     }
     OrderLayout L;
     order_layout(tot, R.n, L);
     int rk = -1, st = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < NKEY; ++k)
         if (key == k) { rk = off[k] + __popcll(km[k] & ((1ull << lane) - 1ull)); st = L.start[k]; }
     if (rk >= 0) {
         const int pos = key == 0 ? order_pos0(L, rk) : order_posk(L, st, rk);
         R.perm[pos] = e; R.invperm[e] = pos;
     }
-    if (wv == 0 && lane < 8) R.hist_zero[row * 8 + lane] = 0;
+    if (wv == 0 && lane < HSTRIDE) R.hist_zero[row * HSTRIDE + lane] = 0;
 }
 
 // grid (column chunks, n_vf [+ rows of the env order]). A workgroup owns 64 float4 columns of one value function;
@@ -399,7 +423,7 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
     __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
     __shared__ int s_cnt[RED_WAVES * RED_SPW];
-    __shared__ int s_x[4][24];         // the commit rows' exchange area
+    __shared__ int s_x[4][40];         // the commit rows' exchange area
     // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
     const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
     const int rowy = (int)blockIdx.y - R.n_vf;
@@ -489,8 +513,8 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     }
     if (!live) return;
     reinterpret_cast<float4 *>(R.G)[(size_t)k * RED_COLS + i4] = S;
-    if (R.apply && nk > 0) {
-        const float step = R.alpha / (float)nk;
+    if (R.apply && nk > 0 && !(R.fail_flag && *R.fail_flag)) {       // (a step in which a workgroup gave up leaves W as it was)
+        const float step = R.alpha / (float)max(nk, R.nk_floor);
         float4 w = w_old;
         w.x = fmaf(step * sc.x, S.x, w.x); w.y = fmaf(step * sc.y, S.y, w.y);
         w.z = fmaf(step * sc.z, S.z, w.z); w.w = fmaf(step * sc.w, S.w, w.w);
@@ -500,18 +524,18 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
 
 // acting-only steps have no reduce launch: the commit alone, one workgroup of four waves per row of 256 envs
 __global__ __launch_bounds__(256) void commit_kernel(const ReduceArgs R) {
-    __shared__ int s_x[4][24];
+    __shared__ int s_x[4][40];
     commit_and_place_row(R, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, s_x);
 }
 
 __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, const int32_t *n_k, const float *nk_f,
-                                                    const float *scale, float alpha) {
+                                                    const float *scale, float alpha, int nk_floor) {
     const int k = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NACT * NF) return;
     const int nk = n_k ? n_k[k] : (int)(nk_f[k] + 0.5f);     // packed operand: counts summed as floats (exact)
     if (nk <= 0) return;
-    const float step = alpha / (float)nk;
+    const float step = alpha / (float)max(nk, nk_floor);
     const int f = i % NF;
     float *w = W + (size_t)k * NACT * NF + i;
     *w = fmaf(step * scale[f], G[(size_t)k * NACT * NF + i], *w);
@@ -519,7 +543,7 @@ __global__ __launch_bounds__(256) void apply_kernel(float *W, const float *G, co
 
 // The order-pinned multi-rank form (SPEC §5): G and the counts are the sums of the ranks' packed operands in slot order.
 __global__ __launch_bounds__(256) void apply_slots_kernel(float *W, const float *slots, int n_slots, long stride, int n_vf,
-                                                          const float *scale, float alpha) {
+                                                          const float *scale, float alpha, int nk_floor) {
     const int k = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= NACT * NF) return;
@@ -531,7 +555,7 @@ __global__ __launch_bounds__(256) void apply_slots_kernel(float *W, const float 
     }
     const int nk = (int)(nkf + 0.5f);
     if (nk <= 0) return;
-    const float step = alpha / (float)nk;
+    const float step = alpha / (float)max(nk, nk_floor);
     float *w = W + at;
     *w = fmaf(step * scale[i % NF], g, *w);
 }
@@ -540,65 +564,63 @@ __global__ __launch_bounds__(256) void apply_slots_kernel(float *W, const float 
 // SPEC §5 env order: stable counting sort of the envs by option_id (6 keys), two tiny kernels per step.
 // Option-homogeneous workgroups turn five sparse option passes per workgroup into about one dense one.
 __global__ __launch_bounds__(256) void sort_hist_kernel(const int32_t *option_id, int n, int n_vf, int32_t *hist) {
-    __shared__ int s_c[4][8];
+    __shared__ int s_c[4][HSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = blockIdx.x * 256 + tid;
-    int o = e < n ? option_id[e] : -1;
-    if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;          // out-of-range ids sort last (key n_vf <= 6)
+    const int o = e < n ? sort_key(option_id[e], n_vf) : -1;          // (out-of-range ids sort last)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NKEY; ++k) {
         const uint64_t m = __ballot(o == k);
         if (lane == 0) s_c[wave][k] = __popcll(m);
     }
     __syncthreads();
-    if (tid < 7) hist[blockIdx.x * 8 + tid] = s_c[0][tid] + s_c[1][tid] + s_c[2][tid] + s_c[3][tid];
+    if (tid < NKEY) hist[blockIdx.x * HSTRIDE + tid] = s_c[0][tid] + s_c[1][tid] + s_c[2][tid] + s_c[3][tid];
 }
 
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option_id, int n, int n_vf, int nblk,
                                                            const int32_t *hist, int32_t *perm, int32_t *invperm) {
-    __shared__ int s_c[4][8];
-    __shared__ int s_off[8];
+    __shared__ int s_c[4][HSTRIDE];
+    __shared__ int s_off[HSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     // offset of (key k, block b) in the sorted order = (all envs with a smaller key) + (key-k envs of earlier blocks)
-    __shared__ int s_tot[8], s_pre[8], s_part[4][16];
-    int tot[7], pre[7];
+    __shared__ int s_tot[HSTRIDE], s_pre[HSTRIDE], s_part[4][2 * HSTRIDE];
+    int tot[NKEY], pre[NKEY];
 #pragma unroll
-    for (int kk = 0; kk < 7; ++kk) { tot[kk] = 0; pre[kk] = 0; }
+    for (int kk = 0; kk < NKEY; ++kk) { tot[kk] = 0; pre[kk] = 0; }
     for (int bb0 = 0; bb0 < nblk; bb0 += 256) {
         const int bb = bb0 + tid;
         if (bb < nblk) {
 #pragma unroll
-            for (int kk = 0; kk < 7; ++kk) {
-                const int h = hist[bb * 8 + kk];
+            for (int kk = 0; kk < NKEY; ++kk) {
+                const int h = hist[bb * HSTRIDE + kk];
                 tot[kk] += h;
                 if (bb < b) pre[kk] += h;
             }
         }
     }
 #pragma unroll
-    for (int kk = 0; kk < 7; ++kk) {                       // integer sums: any order
+    for (int kk = 0; kk < NKEY; ++kk) {                       // integer sums: any order
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) { tot[kk] += __shfl_xor(tot[kk], m, 64); pre[kk] += __shfl_xor(pre[kk], m, 64); }
-        if (lane == 0) { s_part[wave][kk] = tot[kk]; s_part[wave][8 + kk] = pre[kk]; }
+        if (lane == 0) { s_part[wave][kk] = tot[kk]; s_part[wave][HSTRIDE + kk] = pre[kk]; }
     }
     __syncthreads();
-    if (tid < 7) {
+    if (tid < NKEY) {
         s_tot[tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
-        s_pre[tid] = s_part[0][8 + tid] + s_part[1][8 + tid] + s_part[2][8 + tid] + s_part[3][8 + tid];
+        s_pre[tid] = s_part[0][HSTRIDE + tid] + s_part[1][HSTRIDE + tid] + s_part[2][HSTRIDE + tid] + s_part[3][HSTRIDE + tid];
     }
     __syncthreads();
-    int tt[7];
+    int tt[NKEY];
 #pragma unroll
-    for (int kk = 0; kk < 7; ++kk) tt[kk] = s_tot[kk];
+    for (int kk = 0; kk < NKEY; ++kk) tt[kk] = s_tot[kk];
     OrderLayout L;
     order_layout(tt, n, L);
-    if (tid < 7) s_off[tid] = s_pre[tid];               // rank of the row's first key-k env within its run
+    if (tid < NKEY) s_off[tid] = s_pre[tid];               // rank of the row's first key-k env within its run
     const int e = b * 256 + tid;
-    int o = e < n ? option_id[e] : -1;
-    if (o < 0 || o >= n_vf) o = e < n ? n_vf : -1;
+    const int o = e < n ? sort_key(option_id[e], n_vf) : -1;
     int rank = 0;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < NKEY; ++k) {
         const uint64_t m = __ballot(o == k);
         if (lane == 0) s_c[wave][k] = __popcll(m);
         if (o == k) rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -609,7 +631,7 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const int32_t *option
         for (int w = 0; w < wave; ++w) rk += s_c[w][o];
         int st = 0;
 #pragma unroll
-        for (int k = 1; k < 7; ++k) if (o == k) st = L.start[k];
+        for (int k = 1; k < NKEY; ++k) if (o == k) st = L.start[k];
         const int pos = o == 0 ? order_pos0(L, rk) : order_posk(L, st, rk);
         perm[pos] = e;
         invperm[e] = pos;
@@ -932,8 +954,10 @@ struct scg_ctx {
     unsigned long long *d_fit_part;   // fit_kernel: tagged workgroup partials [FIT_BATCH][2][FIT_G][8]
     uint32_t *h_async;             // pinned, device-visible status word: kernels that give up OR their reason into it
     uint32_t *d_async;             // ... its device address
+    int32_t *d_fail;               // device-side twin of the step's give-up bit (read by the reduce launch of the same step)
     double fit_timeout_s;          // how long fit_kernel waits for a workgroup that is not running yet
     float4 *d_outrec;              // [nblk * BLOCK_ENVS][OREC] per-position step results (td_kernel -> commit_row)
+    float4 *d_qalt;                // [nblk * BLOCK_ENVS][2] the root's Q(s', .) of envs about to enter an option (SPEC §4.2)
     int32_t *d_invperm;            // [n_envs] position of each env in d_perm
     int32_t *d_hist2[2];           // per-row counts of the option ids a learning step leaves (double-buffered)
     int hist_parity;
@@ -1051,6 +1075,12 @@ int scg_async_status(scg_ctx *c, void *stream, int32_t synchronize, uint32_t *wo
 int scg_clear_async_error(scg_ctx *c) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_clear_async_error: null ctx");
     if (c->h_async) *reinterpret_cast<volatile uint32_t *>(c->h_async) = 0u;
+    // a step that gave up was voided on the device (no apply, no commit): whatever it left half-made is dropped here
+    if (c->d_fail) {
+        DeviceGuard g(c->cfg.device);
+        if (g.ok) (void)hipMemset(c->d_fail, 0, sizeof(int32_t));
+    }
+    c->order_valid = false; c->hist_dirty = true; c->arm_rows_ready = false;
     return SCG_OK;
 }
 
@@ -1089,6 +1119,9 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
     if (cfg->n_envs < 1) return fail(nullptr, SCG_ERR_INVALID, "scg_create: n_envs must be >= 1");
     if (cfg->n_options < 0 || cfg->n_options > SCG_MAX_OPTIONS)
         return fail(nullptr, SCG_ERR_INVALID, "scg_create: n_options out of range [0,5]");
+    if (cfg->update_count_floor < 0) return fail(nullptr, SCG_ERR_INVALID, "scg_create: update_count_floor must be >= 0");
+    if (cfg->reoffer_period < 0 || (cfg->reoffer_period & (cfg->reoffer_period - 1)))
+        return fail(nullptr, SCG_ERR_INVALID, "scg_create: reoffer_period must be a power of two (or 0)");
     if (cfg->fourier_order != SCG_FOURIER_ORDER)
         return fail(nullptr, SCG_ERR_INVALID, "scg_create: only Fourier order 5 is built");
     int ndev = 0;
@@ -1114,16 +1147,18 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMalloc(&c->d_edges, MAX_EDGES * 8 * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_scale, NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_perm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipMalloc(&c->d_hist, (size_t)c->nblk * 8 * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_hist, (size_t)((c->cfg.n_envs + 255) / 256) * HSTRIDE * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_collect_rows, (size_t)((cfg->n_envs + COL_ROW - 1) / COL_ROW + 1) * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_fit_part, (size_t)FIT_BATCH * 2 * FIT_G * 8 * sizeof(unsigned long long)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipHostMalloc(reinterpret_cast<void **>(&c->h_async), 64, hipHostMallocMapped) != hipSuccess) { st = SCG_ERR_HIP; break; }
         *c->h_async = 0u;
         if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_async), c->h_async, 0) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_fail, sizeof(int32_t)) != hipSuccess || hipMemset(c->d_fail, 0, sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_outrec, (size_t)c->nblk * BLOCK_ENVS * OREC * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        if (hipMalloc(&c->d_qalt, (size_t)c->nblk * BLOCK_ENVS * 2 * sizeof(float4)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMalloc(&c->d_invperm, (size_t)c->nblk * BLOCK_ENVS * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         {
-            const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * 8 * sizeof(int32_t);
+            const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * HSTRIDE * sizeof(int32_t);
             if (hipMalloc(&c->d_hist2[0], hb) != hipSuccess || hipMalloc(&c->d_hist2[1], hb) != hipSuccess) { st = SCG_ERR_HIP; break; }
             if (hipMemset(c->d_hist2[0], 0, hb) != hipSuccess || hipMemset(c->d_hist2[1], 0, hb) != hipSuccess) { st = SCG_ERR_HIP; break; }
         }
@@ -1158,9 +1193,9 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
 int scg_destroy(scg_ctx *c) {
     if (!c) return SCG_OK;
     (void)hipFree(c->d_slabs); (void)hipFree(c->d_cnts); (void)hipFree(c->d_G); (void)hipFree(c->d_nk);
-    (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]); (void)hipFree(c->d_outrec); (void)hipFree(c->d_invperm);
+    (void)hipFree(c->d_hist2[0]); (void)hipFree(c->d_hist2[1]); (void)hipFree(c->d_outrec); (void)hipFree(c->d_qalt); (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_edges); (void)hipFree(c->d_starts); (void)hipFree(c->d_scale); (void)hipFree(c->d_cellmask); (void)hipFree(c->d_perm); (void)hipFree(c->d_hist);
-    (void)hipFree(c->d_fit_part); (void)hipFree(c->d_collect_rows);
+    (void)hipFree(c->d_fit_part); (void)hipFree(c->d_collect_rows); (void)hipFree(c->d_fail);
     if (c->h_async) (void)hipHostFree(c->h_async);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
@@ -1171,11 +1206,14 @@ int scg_destroy(scg_ctx *c) {
 }
 
 int scg_set_hparams(scg_ctx *c, float gamma, float alpha, float epsilon, float r_option_success,
-                    int32_t max_episode_steps, int32_t max_option_steps) {
+                    int32_t max_episode_steps, int32_t max_option_steps, int32_t update_count_floor, int32_t reoffer_period) {
     if (!c) return fail(nullptr, SCG_ERR_INVALID, "scg_set_hparams: null ctx");
     c->cfg.gamma = gamma; c->cfg.alpha = alpha; c->cfg.epsilon = epsilon;
     c->cfg.r_option_success = r_option_success;
     c->cfg.max_episode_steps = max_episode_steps; c->cfg.max_option_steps = max_option_steps;
+    c->cfg.update_count_floor = update_count_floor < 0 ? 0 : update_count_floor;
+    if (reoffer_period < 0 || (reoffer_period & (reoffer_period - 1))) return fail(c, SCG_ERR_INVALID, "scg_set_hparams: reoffer_period must be a power of two (or 0)");
+    c->cfg.reoffer_period = reoffer_period;
     return SCG_OK;
 }
 
@@ -1228,6 +1266,7 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.seed = c->cfg.seed; A.env_base = c->cfg.env_id_base;
     A.gamma = c->cfg.gamma; A.epsilon = c->cfg.epsilon; A.r_succ = c->cfg.r_option_success;
     A.max_ep = c->cfg.max_episode_steps; A.max_opt = c->cfg.max_option_steps;
+    A.reoffer_mask = c->cfg.reoffer_period > 1 ? (uint32_t)(c->cfg.reoffer_period - 1) : 0u;
     A.ms = c->ms;
     A.edges = c->d_edges; A.starts = c->d_starts; A.cellmask = c->d_cellmask;
     A.slabs = c->d_slabs; A.cnts = c->d_cnts;
@@ -1236,7 +1275,7 @@ static void fill_common(const scg_ctx *c, StepArgs &A) {
     A.ring_x = c->ring_x; A.ring_y = c->ring_y; A.events = c->events; A.ev_len = c->ev_len;
     A.ring_mask = c->ring_len > 0 ? c->ring_len - 1 : 0;
     A.stamps = c->d_stamps;
-    A.async_word = c->d_async;
+    A.async_word = c->d_async; A.fail_flag = c->d_fail;
 }
 
 // The reduce launch; for the fused step (`st` given) its extra workgroups also commit the step's per-position
@@ -1246,11 +1285,11 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
     ReduceArgs R;
     memset(&R, 0, sizeof(R));
     R.slabs = c->d_slabs; R.cnts = c->d_cnts; R.G = c->G_out; R.n_k = c->nk_out; R.nk_f = c->nkf_out; R.W = W; R.scale = c->d_scale;
-    R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply;
+    R.nblk = nblk; R.n_vf = c->n_vf; R.alpha = c->cfg.alpha; R.apply = apply; R.fail_flag = c->d_fail; R.nk_floor = c->cfg.update_count_floor;
     const int nrow = st ? (c->cfg.n_envs + 255) / 256 : 0;
     R.n = c->cfg.n_envs; R.nrow = nrow;
     if (st) {
-        R.outrec = c->d_outrec; R.invperm = c->d_invperm; R.perm = c->d_perm; R.sort = sort ? 1 : 0;
+        R.outrec = c->d_outrec; R.qalt = c->d_qalt; R.invperm = c->d_invperm; R.perm = c->d_perm; R.sort = sort ? 1 : 0;
         R.hist = c->d_hist2[c->hist_parity]; R.hist_zero = c->d_hist2[c->hist_parity ^ 1];
         R.x = st->x; R.y = st->y; R.vx = st->vx; R.vy = st->vy; R.reward = st->reward;
         R.option_id_out = st->option_id; R.opt_steps = st->opt_steps; R.ep_steps = st->ep_steps;
@@ -1320,14 +1359,14 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
     }
     c->order_valid = false;
     if (c->hist_dirty) {
-        const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * 8 * sizeof(int32_t);
+        const size_t hb = (size_t)((c->cfg.n_envs + 255) / 256) * HSTRIDE * sizeof(int32_t);
         SCG_HIP(c, hipMemsetAsync(c->d_hist2[0], 0, hb, s));
         SCG_HIP(c, hipMemsetAsync(c->d_hist2[1], 0, hb, s));
         c->hist_dirty = false;
     }
     const bool fold = (flags & SCG_STEP_LEARN) && !(flags & 0x200u);      // 0x200: diagnostic, sort afresh every step
     A.hist_next = fold ? c->d_hist2[c->hist_parity] : nullptr;
-    A.perm = c->d_perm; A.outrec = c->d_outrec;
+    A.perm = c->d_perm; A.outrec = c->d_outrec; A.qalt = c->d_qalt;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->prof_on && (c->prof_seen++ % c->prof_every) == c->prof_every / 2) {     // (not the first launch into an idle queue)
         if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
@@ -1520,7 +1559,7 @@ int scg_apply_update_packed(scg_ctx *c, float *W, const float *G_packed, void *s
     SCG_ON_DEVICE(c, "scg_apply_update_packed");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G_packed,
-                       (const int32_t *)nullptr, G_packed + (size_t)c->n_vf * NACT * NF, c->d_scale, c->cfg.alpha);
+                       (const int32_t *)nullptr, G_packed + (size_t)c->n_vf * NACT * NF, c->d_scale, c->cfg.alpha, c->cfg.update_count_floor);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
@@ -1534,7 +1573,7 @@ int scg_apply_update_slots(scg_ctx *c, float *W, const float *slots, int32_t n_s
     SCG_ON_DEVICE(c, "scg_apply_update_slots");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_slots_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, slots, (int)n_slots,
-                       (long)slot_stride, c->n_vf, c->d_scale, c->cfg.alpha);
+                       (long)slot_stride, c->n_vf, c->d_scale, c->cfg.alpha, c->cfg.update_count_floor);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
@@ -1546,7 +1585,7 @@ int scg_apply_update(scg_ctx *c, float *W, const float *G, const int32_t *n_k, v
     SCG_ON_DEVICE(c, "scg_apply_update");
     dim3 grid((NACT * NF + 255) / 256, c->n_vf);
     hipLaunchKernelGGL(apply_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, G, n_k,
-                       (const float *)nullptr, c->d_scale, c->cfg.alpha);
+                       (const float *)nullptr, c->d_scale, c->cfg.alpha, c->cfg.update_count_floor);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }

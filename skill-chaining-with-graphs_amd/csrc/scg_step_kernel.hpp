@@ -108,6 +108,8 @@ constexpr int M_INTS = 128;
 static_assert(LIST_WAVES * 16 <= M_GROUPS && P_WAVES <= 4, "s_misc layout");
 
 enum { MODE_FUSED = 0, MODE_TRANS = 1, MODE_QVAL = 2 };
+constexpr unsigned IA_ENTERING = 0x40u;     // s_ia bit 6: the env is about to ENTER option s_on (SPEC §4.2 value-gated entry)
+constexpr unsigned OREC_DECLINED = 0x7fc0deadu;   // result line word [3].y: the env stays with the root after all (commit_row: option 0, the root's Q values)
 // Build-time knobs for tools/ab_bench.py (the variants measured and dropped in round 4 — evaluation-only value functions on the
 // vector pipe or behind the passes, static deals of E's and U1's units, E rebalancing — are kept as
 // profiles/r04_dropped_kernel_variants.diff with their numbers in profiles/r04_td_kernel_ab_log.txt).
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         const int e = e_pre;
         if (MODE == MODE_FUSED) {
             uint32_t u[4] = {0u, 0u, 0u, 0u};
-            int a = NACT - 1, ep0 = 0, o = 0, osteps = 0;
+            int a = NACT - 1, ep0 = 0, o = 0, o_in = 0, osteps = 0;
             float sx = 0.5f, sy = 0.5f, svx = 0.0f, svy = 0.0f;
             float qc[NACT] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             if (valid) {
@@ -558,6 +560,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
                 for (int aa = 0; aa < NACT; ++aa) qc[aa] = A.qcache[(size_t)aa * N + e];
                 ep0 = A.ep_steps[e]; o = A.option_id[e]; osteps = A.opt_steps[e];
+                o_in = o;                              // (-k: inside option k's initiation set, staying out of it — SPEC §4.2)
+                o = max(o, 0);
                 s_s[0 * BLOCK_ENVS + i] = sx; s_s[1 * BLOCK_ENVS + i] = sy;
                 s_s[2 * BLOCK_ENVS + i] = svx; s_s[3 * BLOCK_ENVS + i] = svy;
                 s_ot[i] = (uint8_t)o;
@@ -680,9 +684,14 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     if (par2 != 0 && ((inB >> par2) & 1u)) tgtB |= 1u << k;
                 }
                 const unsigned sel = inB & ~tgtB & A.enabled;         // a gestating option is never selected
-                const int on = keep ? o : (sel ? __builtin_ctz(sel) : 0);
+                const int cand = keep ? o : (sel ? __builtin_ctz(sel) : 0);
+                // SPEC §4.2: an env that stayed out of option k (option_id = -k) and still has k as its candidate is offered k again only
+                // every reoffer_period-th step (staggered by env id; a new episode is a new offer) — in between it stays out without
+                // a new comparison, i.e. without the option's value function being evaluated for it
+                const int stay = (!keep && cand >= 1 && dn == 0 && o_in == -cand && (((uint32_t)A.t + (uint32_t)(A.env_base + e)) & A.reoffer_mask) != 0u) ? cand : 0;
+                const int on = stay ? 0 : cand;
                 s_on[i] = (uint8_t)on;
-                s_gs[i] = (uint8_t)inS; s_ia[i] = (uint8_t)((inA & 0x3Eu) | (goal ? 1u : 0u));
+                s_gs[i] = (uint8_t)inS; s_ia[i] = (uint8_t)((inA & 0x3Eu) | (goal ? 1u : 0u) | ((!keep && on >= 1) ? IA_ENTERING : 0u));
                 {   // bit masks of the VFs with items / update items here: OR over the wave's lanes first, then one LDS atomic per wave
                     const unsigned pm = (1u << (o & 31)) | (1u << (on & 31)) | inS, um = (1u << (o & 31)) | inS;
                     unsigned pw = 0, uw = 0;
@@ -710,8 +719,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     const int osn = keep ? osteps + 1 : 0, epn = dn ? 0 : eps1;
                     float4 *orec = A.outrec + (size_t)(e0 + i) * OREC;
                     orec[0] = make_float4(nx, ny, nvx, nvy);
-                    orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16)),
+                    orec[1] = make_float4(rew, __uint_as_float((unsigned)a | ((unsigned)dn << 8) | ((unsigned)on << 16) | ((unsigned)stay << 28)),
                                           __int_as_float(osn), __int_as_float(epn));
+                    reinterpret_cast<float *>(orec + 3)[1] = 0.0f;        // not declined (this lane alone writes the word: here and in gate())
                 }
                 SCG_LITEP(5);
                 SCG_STAMP(19);                                        // P: bookkeeping, option logic, result line
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     A.ring_x[row] = s_s[0 * BLOCK_ENVS + i]; A.ring_y[row] = s_s[1 * BLOCK_ENVS + i];
                 }
                 if (A.events) { A.events[e] = (uint8_t)((goal ? 1u : 0u) | (inA & 0x3Eu)); A.ev_len[e] = eps1; }
-                hkey = (e >> 8) * 8 + on;                             // next step's counting sort: (row of 256 envs, option id)
+                hkey = (e >> 8) * 8 + on;                             // next step's counting sort: (row of 256 envs, option id; a declined entry is moved to 0 by gate())
             } else {
                 s_on[i] = 255; s_gs[i] = 0; s_ia[i] = 0;
             }
@@ -820,6 +830,9 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
             }
         }
+#ifdef SCG_TEST_DROP_ARRIVE      // (fault-injection build, tests/test_gpu_robustness.py: the REAL give-up path, once) helper wave 0 of block 1 never arrives at step t = 0x7e57
+        if (!(hw == 0 && blockIdx.x == 1 && A.t == 0x7e57ull))
+#endif
         lds_arrive(&s_misc[M_C_HELP], 1);
         lds_await(&s_misc[M_C_HELP], N_HELP);                                  // W_0, W_kB, Z(s) and the list are complete
         SCG_HSTAMP(14);
@@ -876,7 +889,34 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     if (MODE == MODE_FUSED && tid < A.n_vf && A.cnts && tid != 0 && tid != kB && !((single >> tid) & 1u))
         A.cnts[(size_t)b * A.n_vf + tid] = 0;               // value functions without a pass here leave no slab
     const int n_pass0 = A.k_hi >= A.k_lo ? 1 : 0;
-    for (int pass = 0; pass < n_pass0 + MAX_VF; ++pass) {
+    const unsigned single0 = single;
+    bool gate0_done = false, root_saved = false;
+    // SPEC §4.2 value-gated entry. An env about to enter option k (s_on, IA_ENTERING) does so only if the option promises at least
+    // what the root does from s_next: max_a Q_k(s_next, a) >= max_a Q_0(s_next, a), both as E left them in LDS. kdec < 0: the
+    // candidates evaluated in pass 0 (the block's option, value functions without a pass of their own); kdec = k: option k's own
+    // single pass has just run. A declined env gets option 0 in the block's flags, the mark in its result line (commit_row then takes
+    // the root's Q values the root's unit left beside the line) and its share of the next order's histogram moved to key 0.
+    auto gate = [&](int kdec) {
+        if (MODE != MODE_FUSED || tid >= nb || !(s_ia[tid] & IA_ENTERING)) return;
+        const int cand = s_on[tid];
+        const bool mine = kdec < 0 ? (cand >= 1 && cand < MAX_VF && !((single0 >> cand) & 1u)) : cand == kdec;
+        if (!mine) return;
+        const float cm = kdec < 0 ? s_maxq[BLOCK_ENVS + tid] : s_maxq[tid];
+        const float rm = kdec < 0 ? s_maxq[tid] : s_qsa[BLOCK_ENVS + tid];
+        if (cm >= rm) return;
+        s_on[tid] = 0;
+        reinterpret_cast<float *>(A.outrec + (size_t)(e0 + tid) * OREC + 3)[1] = __uint_as_float(OREC_DECLINED);
+        if (A.hist_next) {
+            const int e = A.perm ? A.perm[e0 + tid] : e0 + tid;
+            atomicAdd(&A.hist_next[(e >> 8) * 8 + cand], -1);
+            atomicAdd(&A.hist_next[(e >> 8) * 8], 1);
+        }
+    };
+    // A hand-off poll of phase P that ran out leaves LDS data unpublished (lists, tables, the physics' results): the block goes inert —
+    // no pass, no slab, counts 0 — instead of computing on them; the step as a whole is voided by the reduce launch
+    const bool blk_fail = MODE == MODE_FUSED && __builtin_amdgcn_readfirstlane(s_misc[M_FAIL]) != 0;
+    if (blk_fail && tid < A.n_vf && A.cnts) A.cnts[(size_t)b * A.n_vf + tid] = 0;
+    for (int pass = 0; pass < n_pass0 + MAX_VF && !blk_fail; ++pass) {
         // Opaque copies of the thread and lane ids for the pass: every per-lane address of the pass body is loop-invariant, and
         // hoisted out of the pass loop they all stay live across it — the register allocator then spills them to scratch.
         // (Re-made from the hardware lane counter rather than copied from the kernel's tid: kept live across the loop the copy
@@ -897,6 +937,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         const bool u1_done = helpers && pass == 0;          // the helper waves ran U1 and built the list under phase P
         if (pass > 0) block_lds_sync();                     // (pass 0 starts behind the barrier that ends phase P)
+        if (MODE == MODE_FUSED && pass > 0 && !root_saved) {      // the root's max_a Q_0(s_next, a) of pass 0, before this pass's E reuses s_maxq
+            if (tid < nb) s_qsa[BLOCK_ENVS + tid] = s_maxq[tid];  // (s_qsa's second half: value function B's Q(s, a), pass 0 only)
+            root_saved = true;
+        }
         SCG_STAMP(pass == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
         // ---- per-env flags of the pass (SPEC §5): ev bit v = the env needs Q_v(s_next, .) (bootstrap target and/or next
         // action); update items of A (all of them in pass 0 of a fused step: the root updates on every env) with their action
@@ -923,7 +967,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 }
                 s_rk[ft] = rk; s_ck[ft] = cont;
             }
-            evA = (on == kA) || (up && cont > 0.0f);
+            evA = (on == kA) || (up && cont > 0.0f) || (MODE == MODE_FUSED && kA == 0 && (s_ia[ft] & IA_ENTERING));      // (SPEC §4.2: the gate compares with the root)
             if (kBp >= 1) evB = (on == kBp) || (ot == kBp && A.learn && s_co[ft] > 0.0f);
             at = s_a[ft];
             s_ev[ft] = (uint8_t)((evA ? 1 : 0) | (evB ? 2 : 0));
@@ -1105,6 +1149,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     float4 *orec = A.outrec + (size_t)(e0 + il) * OREC;
                     orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
                     orec[3].x = qo[4];
+                    float mx = qo[0];
+#pragma unroll
+                    for (int a = 1; a < NACT; ++a) mx = fmaxf(mx, qo[a]);
+                    s_maxq[BLOCK_ENVS + il] = mx;              // SPEC §4.2: what the option promises (slot 1: the env has no item of B that reads it)
                 }
                 wave_lds_sync();
                 continue;
@@ -1117,6 +1165,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 if (out_lane && have && ((s_ev[il] >> v) & 1)) {
                     const int kv = v ? kBp : kA;
                     if (MODE == MODE_FUSED) {             // into the env's result line; commit_row writes qcache
+                        if (kv == 0 && (s_ia[il] & IA_ENTERING)) {      // SPEC §4.2: the root's values, should the env stay with the root after all
+                            float4 *qa = A.qalt + (size_t)(e0 + il) * 2;
+                            qa[0] = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                            qa[1].x = qo[4];
+                        }
                         if (s_on[il] == kv) {
                             float4 *orec = A.outrec + (size_t)(e0 + il) * OREC;
                             orec[2] = make_float4(qo[0], qo[1], qo[2], qo[3]);
@@ -1215,7 +1268,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 if (j < rl) {
                     const int li = ro + j, il = s_ulist[li];
                     const float rr = rA[il], cont = cA[il];
-                    const float target = cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr;
+                    // SPEC §4.2 exit rule (single passes of an option): the option ended (continuation 0) but the episode goes on -> the
+                    // root's value of where the env goes next (kept in s_qsa's second half by the first single pass)
+                    const bool boot = MODE == MODE_FUSED && kA != 0 && cont == 0.0f && s_c0[il] > 0.0f;
+                    const float target = boot ? fmaf(A.gamma, s_qsa[BLOCK_ENVS + il], rr) : (cont > 0.0f ? fmaf(cont, s_maxq[il], rr) : rr);
                     const float d = target - s_qsa[li];
                     float2 ab[6], cd[6];
                     item_entries(s_z1 + (il * 2 + 0) * 4, cp9, ab, cd);
@@ -1226,7 +1282,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                     }
                     if (j < nbq) {                           // the item also updates value function B
                         const float rb = s_ro[il], cb2 = s_co[il];
-                        const float tb = cb2 > 0.0f ? fmaf(cb2, s_maxq[BLOCK_ENVS + il], rb) : rb;
+                        const float tb = (cb2 == 0.0f && s_c0[il] > 0.0f) ? fmaf(A.gamma, s_maxq[il], rb)          // (exit rule: s_maxq[il] is the root's max in pass 0)
+                                                                         : (cb2 > 0.0f ? fmaf(cb2, s_maxq[BLOCK_ENVS + il], rb) : rb);
                         const float db = tb - s_qsa[BLOCK_ENVS + li];
 #pragma unroll
                         for (int c = 0; c < 6; ++c)
@@ -1330,11 +1387,18 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(15);                // slab stores issued
         if (pass == 0) SCG_LITE(7);                         // pass 0 done (slab stores issued)
+        if (pass == 0) { gate(-1); gate0_done = true; } else gate(kA);
+    }
+    if (MODE == MODE_FUSED && n_pass0 && !blk_fail && !gate0_done) {      // acting-only steps: pass 0 ended behind E, without a barrier
+        block_lds_sync();
+        gate(-1);
     }
     if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)
         block_lds_sync();
-        if (tid == 0 && s_misc[M_FAIL])
+        if (tid == 0 && s_misc[M_FAIL]) {
             __hip_atomic_fetch_or(A.async_word, SCG_ASYNC_STEP_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (A.fail_flag) __hip_atomic_store(A.fail_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef SCG_STAMPS_LITE
     if (MODE == MODE_FUSED && A.stamps && lite_role >= 0 && lane == 0) {

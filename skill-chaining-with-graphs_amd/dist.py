@@ -41,7 +41,8 @@ def allreduce_packed(gp: torch.Tensor, group=None) -> None:
 
 def allgather_packed(gp: torch.Tensor, slots: torch.Tensor, group=None) -> None:
     """Every rank's packed operand into `slots` [world, len(gp)], row r = rank r — the operand of the order-pinned sum
-    (scg_apply_update_slots): ONE all-gather per step instead of the all-reduce; bit-identical weights on every rank count."""
+    (scg_apply_update_slots): ONE all-gather per step instead of the all-reduce; weights identical on every rank of a run and
+    reproducible by the oracle for any number of ranks (the rank count is part of the run's identity)."""
     import torch.distributed as dist
     if _via_host(gp, group):
         sc = torch.empty(slots.numel(), dtype=slots.dtype)

@@ -22,6 +22,8 @@ ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3]); ap.add_argum
 ap.add_argument("--rules", type=int, nargs="+", default=[0, 1, 2]); ap.add_argument("--r-succ", type=float, nargs="+", default=[50.0, 1000.0, 10000.0])
 ap.add_argument("--max-option-steps", type=int, default=200)
 ap.add_argument("--arms", nargs="+", default=None, help="explicit arms rule:r_succ (e.g. 0:10000 2:50) instead of the rules x r-succ grid")
+ap.add_argument("--reoffer", type=int, default=1, help="SPEC 4.2: an env staying out of an option is offered it again every this many steps")
+ap.add_argument("--nk-floor", type=int, default=0, help="SPEC 5 apply divisor max(n_k, floor)")
 ap.add_argument("--chunk", type=int, default=0, help="also print the goal rate per chunk of this many step-batches of the `after` window")
 a = ap.parse_args()
 m = scg.load_map(a.map)
@@ -34,6 +36,8 @@ def make(seed, r_succ, rule):
     orc = sc_oracle.Oracle(m, SCALE, n_envs=N, n_options=K, seed=seed, enabled_mask=0, n_threads=a.threads, gamma=0.99, alpha=a.alpha,
                            epsilon=0.05, r_option_success=r_succ, max_episode_steps=2000, max_option_steps=a.max_option_steps)
     orc.p.exit_rule = rule % 10
+    orc.p.nk_floor = a.nk_floor
+    orc.p.reoffer_period = a.reoffer
     orc.p.select_rule = rule // 10          # (rules >= 10: value-gated entry on top of exit rule rule % 10)
     orc.set_trace(64)
     return orc

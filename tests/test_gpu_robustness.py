@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from gpu_util import dev, make_pair
+from util import HP, chain_classifiers, random_states, random_weights
 from skill_chaining_with_graphs_amd._lib import ScgError
 
 pytestmark = pytest.mark.gpu
@@ -153,3 +154,44 @@ def test_announced_trigger_buffers_are_held_and_validated():
         ctx.step(st, W, clf, 0, 2)
     ctx.step(st, W, clf, 0, 2)                                             # disarmed by the refusal: steps run again
     assert ctx.async_status(synchronize=True) == 0
+
+
+def test_a_real_handoff_give_up_voids_the_step_and_is_reported():
+    """the give-up path of the step kernel itself, not its imitation through scg_debug_raise_async. The fault-injection
+    build (csrc/Makefile `faultinj`) drops ONE hand-off on purpose — helper wave 0 of block 1 never arrives at step t = 0x7e57 — so
+    the other helper waves' bounded poll runs out for real. Expected: the block goes inert, the reduce launch of the same step
+    neither applies the update nor commits results (state and weights stay what the previous step left), the status word names the
+    step, every later launch is refused until the error is cleared, and the context runs on afterwards."""
+    import os
+    import skill_chaining_with_graphs_amd as scg
+    from skill_chaining_with_graphs_amd.core import EnvState, ScgContext
+    path = os.path.join(os.path.dirname(scg.LIB_PATH), "libscg_hip_faultinj.so")
+    if not os.path.exists(path):
+        pytest.skip("fault-injection build missing (make -C skill-chaining-with-graphs_amd/csrc faultinj)")
+    m = scg.load_map("pinball_simple")
+    n, T = 1024, 0x7e57
+    ctx = ScgContext(n, 1, m, seed=3, block_envs=256, library=path, **HP)
+    st = EnvState(n, ctx.device, m)
+    x, y, vx, vy = random_states(m, n, 5, vmax=1.0)
+    for k, v in (("x", x), ("y", y), ("vx", vx), ("vy", vy)):
+        getattr(st, k).copy_(dev(v))
+    W = dev(random_weights(2, 7, std=0.05)).view(-1)
+    clf = dev(chain_classifiers(m, 1)).view(-1)
+    for t in (T - 2, T - 1):
+        ctx.step(st, W, clf, 0b10, t)
+    assert ctx.async_status(synchronize=True) == 0
+    keys = ("x", "y", "vx", "vy", "option_id", "opt_steps", "ep_steps", "qcache", "action", "reward", "done")
+    before = {k: getattr(st, k).clone() for k in keys}
+    W_before = W.clone()
+    ctx.step(st, W, clf, 0b10, T)                                          # launches fine; gives up on the device
+    with pytest.raises(ScgError, match="hand-off poll"):
+        ctx.async_status(synchronize=True)
+    for k in keys:
+        assert torch.equal(getattr(st, k), before[k]), f"{k} was written by a voided step"
+    assert torch.equal(W, W_before), "a voided step applied its update"
+    with pytest.raises(ScgError, match="hand-off poll"):                   # sticky
+        ctx.step(st, W, clf, 0b10, T + 1)
+    ctx.clear_async_error()
+    ctx.step(st, W, clf, 0b10, T + 1)
+    assert ctx.async_status(synchronize=True) == 0
+    assert not torch.equal(st.x, before["x"])                              # and the context steps again

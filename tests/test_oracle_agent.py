@@ -48,7 +48,7 @@ def test_rollout_invariants_and_determinism():
             G, n_k = orc.step(st, W, clf, t)
             orc.apply(W, G, n_k)
             assert n_k[0] == n and 0 <= n_k[1] <= n and 0 <= n_k[2] <= n
-            assert np.all((st["option_id"] >= 0) & (st["option_id"] <= 2))
+            assert np.all((st["option_id"] >= -2) & (st["option_id"] <= 2))      # (-k: inside I_k, staying out of option k — SPEC §4.2)
             assert np.all(st["action"] < 5) and np.all(st["done"] <= 2)
             assert np.all(np.isfinite(W)) and np.all(np.isfinite(st["qcache"]))
             hist.append((st["x"].copy(), st["option_id"].copy(), st["done"].copy(), n_k.copy()))
@@ -197,3 +197,58 @@ def test_skill_graph_parents_generalise_the_chain():
     st["x"][0], st["y"][0] = 0.8, 0.72               # inside I_1 only: not option 2's target (the goal is) -> 2 fails, 1 selected
     G, n_k = orc.step(st, W, clf, 2)
     assert st["option_id"][0] == 1 and G[2, st["action"][0], 0] == pytest.approx(-5.0)
+
+
+def test_value_gated_entry_and_the_exit_rule_on_one_env():
+    """SPEC §4.2 / §5 (round 5) by construction, one env (global id 0) on the empty map, epsilon = 0, reoffer_period = 4:
+    (a) a candidate option whose value function promises LESS than the root's at s_next is declined: option_id = -k, qcache = the
+        root's Q(s_next, .); while the env stays inside I_k it is offered k again only when (t + env id) % 4 == 0 — raising the
+        option's weights above the root's at t = 1 changes nothing at t = 1, 2, 3 and makes it enter at t = 4;
+    (b) an option that ends while the episode goes on (here: it leaves its initiation set) bootstraps from the ROOT's value of
+        s_next: target = r + gamma * max_a Q_0(s_next, a), checked against float64 values."""
+    orc, m = make_oracle("pinball_empty", n_envs=1, n_options=1, seed=0, epsilon=0.0, enabled_mask=0b10, gamma=0.9, r_option_success=0.0)
+    assert orc.p.reoffer_period == 4 and orc.p.select_rule == 1 and orc.p.exit_rule == 2
+    clf = np.zeros((2, 8), np.float32)
+    clf[1] = disc_weights(0.3, 0.3, 0.12)            # I_1: a disc far from the goal (0.9, 0.9): leaving it is "fail", never "success"
+    W = np.zeros((2, 5, 1296), np.float32)
+    W[0, :, 0] = 2.0                                 # the root promises 2 everywhere (feature 0 = 1), the option 1
+    W[1, :, 0] = 1.0
+    st = sc_oracle.new_state(1, m)
+
+    def park():                                      # back to the disc's centre, at rest (the no-op action keeps it there)
+        st["x"][0], st["y"][0], st["vx"][0], st["vy"][0] = 0.3, 0.3, 0.0, 0.0
+
+    park()
+    orc.step(st, W, clf, 0)
+    assert st["option_id"][0] == -1 and np.allclose(st["qcache"][:, 0], 2.0)          # (a) declined, the root's values cached
+    W[1, :, 0] = 3.0                                 # the option now promises more ...
+    for t in (1, 2, 3):
+        park()
+        orc.step(st, W, clf, t)
+        assert st["option_id"][0] == -1, t                                            # ... but is not offered before t = 4
+    park()
+    orc.step(st, W, clf, 4)
+    assert st["option_id"][0] == 1 and np.allclose(st["qcache"][:, 0], 3.0)           # offered again and entered
+    # (b) throw the env out of I_1 within one step: the option fails, the episode goes on
+    st["x"][0], st["y"][0], st["vx"][0], st["vy"][0] = 0.41, 0.3, 2.0, 0.0
+    s = [st[k].copy() for k in ("x", "y", "vx", "vy")]
+    G, n_k = orc.step(st, W, clf, 5)
+    assert st["option_id"][0] == 0 and n_k.tolist() == [1, 1]
+    a, r = int(st["action"][0]), float(st["reward"][0])
+    phi_s = fourier_reference(*s)[0]
+    sn = [st[k] for k in ("x", "y", "vx", "vy")]
+    v0_next = float(np.max(W[0].astype(np.float64) @ fourier_reference(*sn)[0]))
+    delta = r + 0.9 * v0_next - float(W[1, a].astype(np.float64) @ phi_s)            # bootstrapped from the ROOT (2), not 0 and not the option (3)
+    assert np.allclose(G[1, a], delta * phi_s, rtol=1e-4, atol=1e-4)
+    assert abs(v0_next - 2.0) < 1e-5
+
+
+def test_update_count_floor_divides_small_batches_by_the_floor():
+    """SPEC §5 apply: step = alpha / max(n_k, update_count_floor)."""
+    orc, m = make_oracle("pinball_empty", n_envs=1, n_options=0, alpha=0.5, update_count_floor=4)
+    W = np.zeros((1, 5, 1296), np.float32)
+    G = np.zeros((1, 5, 1296), np.float32); G[0, 2, 0] = 8.0
+    orc.apply(W, G, np.array([1], np.int32))
+    assert W[0, 2, 0] == np.float32(0.5 / 4 * 8.0)                                     # scale_0 = 1; divided by the floor, not by n_k = 1
+    orc.apply(W, G, np.array([16], np.int32))
+    assert W[0, 2, 0] == np.float32(1.0 + 0.5 / 16 * 8.0)

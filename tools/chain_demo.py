@@ -16,7 +16,7 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--gestation", type=int, default=0, help="successes a new option must see before it is enabled (SPEC 4.4)")
 a = ap.parse_args()
 ag = SkillChainingAgent(a.map, a.envs, a.options, seed=a.seed, alpha=a.alpha, epsilon=0.05, gamma=0.99,
-                        max_episode_steps=2000, max_option_steps=200, r_option_success=10000.0)
+                        max_episode_steps=2000, max_option_steps=200, update_count_floor=a.envs // 16)
 ag.enable_tracing(64)
 
 
