@@ -271,17 +271,15 @@ def test_batched_q_learning_learns_pinball():
 
 @pytest.mark.gpu
 def test_the_chain_is_not_worse_than_the_flat_learner_at_equal_env_steps():
-    """The only external anchor this repo has (README.md:2 names the skill-chaining paper, whose claim is that chaining helps): with
-    a completion reward of the goal reward's scale, goal arrivals with the discovered chain stay within a loose factor of the
-    flat learner's over the same env-steps (tools/chain_evidence.py, profiles/r04_chain_evidence_*.txt: 0.96-1.10 over three
-    seeds at 8192 envs). With a SMALL completion reward (50, against step costs of -1 / -5 and a goal worth 10 000) an option
-    whose target is 20+ steps away does better by leaving its initiation set at once — termination is worth 0 — and the chain
-    then HURTS (0.14-0.45 of the flat learner): that regime is the negative control of the profile, not asserted here.
-    Chaotic in the rounding, hence one seed, a loose bound, GPU only, no oracle."""
+    """The only external anchor this repo has (README.md:2 names the skill-chaining paper, whose claim is that chaining helps). With
+    SPEC §4.2's value-gated entry and exit rule (round 5) goal arrivals with the discovered chain are 0.98-1.45 of the flat
+    learner's over the same env-steps on ten seeds at 8192 envs (mean 1.08; profiles/r05_chain_evidence_gpu_a.txt) — rounds 1-4,
+    with forced entry, ranged from 0.15 to 1.15 and collapsed for good whenever the options were cut while the root was still weak.
+    Chaotic in the rounding, hence two seeds, a bound below the measured range, GPU only, no oracle."""
     import torch
     from skill_chaining_with_graphs_amd import SkillChainingAgent
-    hp = dict(alpha=0.02, epsilon=0.05, gamma=0.99, max_episode_steps=2000, max_option_steps=200, r_option_success=10000.0)
     n, warm, after = 4096, 2500, 2000
+    hp = dict(alpha=0.02, epsilon=0.05, gamma=0.99, max_episode_steps=2000, max_option_steps=200, update_count_floor=n // 16)
 
     def run(ag, steps):
         goals = torch.zeros((), device="cuda")
@@ -290,19 +288,20 @@ def test_the_chain_is_not_worse_than_the_flat_learner_at_equal_env_steps():
             goals += (ag.state.done == 1).sum()
         return float(goals) / (steps * n)
 
-    ag = SkillChainingAgent("pinball_simple", n, 3, seed=2, **hp)
-    ag.enable_tracing(64)
-    run(ag, warm)
-    t0 = ag.t
-    report = ag.chain_skills(steps_per_option=400, min_examples=3000, max_examples=40000, start_coverage=0.9)
-    disc = ag.t - t0
-    chain = run(ag, after)
-    flat_ag = SkillChainingAgent("pinball_simple", n, 0, seed=2, **hp)
-    run(flat_ag, warm + disc)
-    flat = run(flat_ag, after)
-    assert len(report) >= 1 and bool(torch.isfinite(ag.W).all())
-    assert chain > 0.6 * flat and chain > 0.0003, (chain, flat, report)
-
+    for seed in (2, 5):
+        ag = SkillChainingAgent("pinball_simple", n, 3, seed=seed, **hp)
+        ag.enable_tracing(64)
+        run(ag, warm)
+        t0 = ag.t
+        report = ag.chain_skills(steps_per_option=400, min_examples=3000, max_examples=40000, start_coverage=0.9)
+        disc = ag.t - t0
+        chain = run(ag, after)
+        flat_ag = SkillChainingAgent("pinball_simple", n, 0, seed=seed, **hp)
+        run(flat_ag, warm + disc)
+        flat = run(flat_ag, after)
+        assert len(report) >= 1 and bool(torch.isfinite(ag.W).all())
+        assert chain > 0.85 * flat and chain > 0.0003, (seed, chain, flat, report)
+        assert int((ag.state.option_id < 0).sum()) > 0           # some envs stay out of an option they are inside of (SPEC §4.2)
 
 @pytest.mark.gpu
 def test_checkpoint_resume_continues_bit_identically(tmp_path):

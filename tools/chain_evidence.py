@@ -22,12 +22,13 @@ ap.add_argument("--warm", type=int, default=3000); ap.add_argument("--after", ty
 ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3])
 ap.add_argument("--gestation", type=int, default=200)
 ap.add_argument("--r-succ", type=float, default=0.0, help="option completion reward (SPEC 4.2 r_option_success)")
+ap.add_argument("--reoffer", type=int, default=4, help="SPEC 4.2 reoffer_period")
 ap.add_argument("--floor-div", type=int, default=16, help="update_count_floor = envs / this (0: no floor)")
 ap.add_argument("--max-option-steps", type=int, default=200)
 ap.add_argument("--json", default=None, help="also write the rows as JSON lines to this file")
 a = ap.parse_args()
 HP = dict(alpha=a.alpha, epsilon=0.05, gamma=0.99, max_episode_steps=2000, max_option_steps=a.max_option_steps, r_option_success=a.r_succ,
-          update_count_floor=(a.envs // a.floor_div if a.floor_div else 0))
+          update_count_floor=(a.envs // a.floor_div if a.floor_div else 0), reoffer_period=a.reoffer)
 print(f"# chain_evidence map {a.map} envs {a.envs} options {a.options} warm {a.warm} after {a.after} gestation {a.gestation} hparams {HP}", flush=True)
 
 
