@@ -169,6 +169,47 @@ __device__ __forceinline__ int sel5(const int (&v)[M], int a) {          // v[a]
     const float *w8 = s_W + W_TAIL + lane_r;                                                                      \
     (void)bi; (void)cp; (void)bcol; (void)ocol_item; (void)out_lane; (void)ab_lane; (void)w4; (void)w8; (void)n16; (void)g
 
+// A zero accumulator made on the spot from an opaque scalar: written as the constant (f4v){0, 0, 0, 0}, LLVM hoists ONE 128-bit zero out of the
+// pass loop, keeps it live across the whole pass in a register tuple and — at 128 VGPRs — spills and reloads that tuple a dozen times per
+// pass (16 MB of scratch writes per launch, round 5) instead of re-making it with four moves.
+__device__ __forceinline__ f4v zero4() {
+    float z = 0.0f;
+    asm volatile("" : "+v"(z));
+    return (f4v){z, z, z, z};
+}
+
+// W_k -> LDS in A-operand order, OUT OF LINE, for the in-pass staging (single-VF passes, steps without helper waves): that path is cold,
+// and inlined into the pass loop its sixteen-byte temporaries took part in the register allocation of the loop's hot stretches — 28 spill /
+// reload sites at pass level (16 MB of scratch writes per launch) instead of 2 (round 5).
+__device__ __attribute__((noinline)) void stage_w_cold(const float *Wk, float *s_dst, int tid) {
+    // (all THREADS threads; every thread's loads are issued before its first LDS store: one memory round trip)
+    struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+    f4v *dst4 = reinterpret_cast<f4v *>(s_dst);
+    constexpr int N4 = 12 * 2 * 64, N1 = 12 * 64;
+    static_assert(2 * THREADS >= N4 && THREADS >= N1, "two float4 and one float per thread");
+    f4v v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int d = tid + i * THREADS;
+        v[i] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+        if (d < N4) {
+            const int t2h = d >> 6, ln = d & 63, row = 16 * (t2h >> 1) + (ln & 15), col = 9 * (ln >> 4) + 4 * (t2h & 1);
+            if (row < NACT * 36) {
+                const F4U w = *reinterpret_cast<const F4U *>(Wk + row * 36 + col);
+                v[i] = (f4v){w.x, w.y, w.z, w.w};
+            }
+        }
+    }
+    float tl = 0.0f;
+    if (tid < N1) {
+        const int ln = tid & 63, row = 16 * (tid >> 6) + (ln & 15);
+        if (row < NACT * 36) tl = Wk[row * 36 + 9 * (ln >> 4) + 8];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int d = tid + i * THREADS; if (d < N4) dst4[d] = v[i]; }
+    if (tid < N1) s_dst[W_TAIL + tid] = tl;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -256,7 +297,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
 #pragma unroll
-                        for (int tt = 0; tt < 3; ++tt) c[v][tt] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int tt = 0; tt < 3; ++tt) c[v][tt] = zero4();
                     }
 #pragma unroll
                     for (int hk = 0; hk < 2; ++hk) {
@@ -890,24 +931,27 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         A.cnts[(size_t)b * A.n_vf + tid] = 0;               // value functions without a pass here leave no slab
     const int n_pass0 = A.k_hi >= A.k_lo ? 1 : 0;
     const unsigned single0 = single;
-    bool gate0_done = false, root_saved = false;
     // SPEC §4.2 value-gated entry. An env about to enter option k (s_on, IA_ENTERING) does so only if the option promises at least
     // what the root does from s_next: max_a Q_k(s_next, a) >= max_a Q_0(s_next, a), both as E left them in LDS. kdec < 0: the
     // candidates evaluated in pass 0 (the block's option, value functions without a pass of their own); kdec = k: option k's own
     // single pass has just run. A declined env gets option 0 in the block's flags, the mark in its result line (commit_row then takes
     // the root's Q values the root's unit left beside the line) and its share of the next order's histogram moved to key 0.
     auto gate = [&](int kdec) {
-        if (MODE != MODE_FUSED || tid >= nb || !(s_ia[tid] & IA_ENTERING)) return;
-        const int cand = s_on[tid];
+        if (MODE != MODE_FUSED) return;
+        int ln;                                             // (the thread id is re-made from the hardware lane counter: the kernel's own `tid`, kept
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));      //  live across the pass loop for this, is what the
+        const int ti = (wave << 6) | ln;                    //  register allocator spills — see the top of the pass loop)
+        if (ti >= nb || !(s_ia[ti] & IA_ENTERING)) return;
+        const int cand = s_on[ti];
         const bool mine = kdec < 0 ? (cand >= 1 && cand < MAX_VF && !((single0 >> cand) & 1u)) : cand == kdec;
         if (!mine) return;
-        const float cm = kdec < 0 ? s_maxq[BLOCK_ENVS + tid] : s_maxq[tid];
-        const float rm = kdec < 0 ? s_maxq[tid] : s_qsa[BLOCK_ENVS + tid];
+        const float cm = kdec < 0 ? s_maxq[BLOCK_ENVS + ti] : s_maxq[ti];
+        const float rm = (kdec >= 0 || single0 != 0u) ? s_qsa[BLOCK_ENVS + ti] : s_maxq[ti];       // (single passes reuse s_maxq's first half: the first of them saved the root's column)
         if (cm >= rm) return;
-        s_on[tid] = 0;
-        reinterpret_cast<float *>(A.outrec + (size_t)(e0 + tid) * OREC + 3)[1] = __uint_as_float(OREC_DECLINED);
+        s_on[ti] = 0;
+        reinterpret_cast<float *>(A.outrec + (size_t)(e0 + ti) * OREC + 3)[1] = __uint_as_float(OREC_DECLINED);
         if (A.hist_next) {
-            const int e = A.perm ? A.perm[e0 + tid] : e0 + tid;
+            const int e = A.perm ? A.perm[e0 + ti] : e0 + ti;
             atomicAdd(&A.hist_next[(e >> 8) * 8 + cand], -1);
             atomicAdd(&A.hist_next[(e >> 8) * 8], 1);
         }
@@ -937,9 +981,8 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         const bool u1_done = helpers && pass == 0;          // the helper waves ran U1 and built the list under phase P
         if (pass > 0) block_lds_sync();                     // (pass 0 starts behind the barrier that ends phase P)
-        if (MODE == MODE_FUSED && pass > 0 && !root_saved) {      // the root's max_a Q_0(s_next, a) of pass 0, before this pass's E reuses s_maxq
-            if (tid < nb) s_qsa[BLOCK_ENVS + tid] = s_maxq[tid];  // (s_qsa's second half: value function B's Q(s, a), pass 0 only)
-            root_saved = true;
+        if (MODE == MODE_FUSED && pass > 0 && kA == __builtin_ctz(single0)) {      // first single pass: save the root's max_a Q_0(s_next, a) of pass 0
+            if (tid < nb) s_qsa[BLOCK_ENVS + tid] = s_maxq[tid];                 // before this pass's E reuses s_maxq (s_qsa's second half: B's Q(s, a), pass 0 only)
         }
         SCG_STAMP(pass == 0 ? 5 : 12);   // (diagnostic) wait at the pass's first barrier
         // ---- per-env flags of the pass (SPEC §5): ev bit v = the env needs Q_v(s_next, .) (bootstrap target and/or next
@@ -1008,9 +1051,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(23);                                       // (diagnostic) flags + ballots
         if (!u1_done) {                                      // (the helper waves staged W_0 / W_kB under phase P)
-            const float *Wa = A.W + (MODE == MODE_QVAL ? 0 : (size_t)kA * NACT * NF);
-            stage_w(Wa, 0, tid, THREADS);
-            if (kBp >= 1) stage_w(A.W + (size_t)kBp * NACT * NF, W_FLOATS, tid, THREADS);
+            // (kA / kBp are wave-uniform: readfirstlane keeps the pointer arithmetic on the scalar unit)
+            const float *Wa = A.W + (MODE == MODE_QVAL ? 0 : (size_t)__builtin_amdgcn_readfirstlane(kA) * NACT * NF);
+            stage_w_cold(Wa, s_W, tid);
+            if (kBp >= 1) stage_w_cold(A.W + (size_t)__builtin_amdgcn_readfirstlane(kBp) * NACT * NF, s_W + W_FLOATS, tid);
         }
         SCG_STAMP(24);                                       // (diagnostic) W staging
         block_lds_sync();
@@ -1238,7 +1282,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) accU[v][s] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int s = 0; s < 3; ++s) accU[v][s] = zero4();
         }
         const float *rA = (MODE == MODE_FUSED && kA != 0) ? s_rk : s_r0, *cA = (MODE == MODE_FUSED && kA != 0) ? s_ck : s_c0;
         const int bi9 = lane_u % 9, cp9 = lane_u / 9;       // builder lanes of a chunk: (slot 9 w + bi9, second index cp9 < 6)
@@ -1387,10 +1431,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         }
         SCG_STAMP(15);                // slab stores issued
         if (pass == 0) SCG_LITE(7);                         // pass 0 done (slab stores issued)
-        if (pass == 0) { gate(-1); gate0_done = true; } else gate(kA);
+        if (pass > 0) gate(kA);
     }
-    if (MODE == MODE_FUSED && n_pass0 && !blk_fail && !gate0_done) {      // acting-only steps: pass 0 ended behind E, without a barrier
-        block_lds_sync();
+    if (MODE == MODE_FUSED && n_pass0 && !blk_fail) {       // the candidates evaluated in pass 0 (their maxima are in s_maxq's second half, which
+        if (!A.learn) block_lds_sync();                     // no later pass touches; acting-only steps: pass 0 ended behind E, without a barrier)
         gate(-1);
     }
     if (MODE == MODE_FUSED && A.async_word) {               // a hand-off poll ran out somewhere in this block: tell the host (sticky)

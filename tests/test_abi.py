@@ -119,3 +119,13 @@ def test_automatic_block_geometry_table(pkg):
     f = pkg.auto_block_envs
     assert [f(n) for n in (1, 4096, 64 * 256, 64 * 256 + 1, 128 * 256, 128 * 256 + 1, 65536, 524288)] == [64, 64, 64, 128, 128, 256, 256, 256]
     assert all(f(n) in pkg.BLOCK_ENVS_BUILDS for n in range(1, 70000, 997))
+
+
+def test_library_and_oracle_agree_on_their_default_hyper_parameters(pkg, oracle_mod):
+    """a library / oracle pair built on defaults must be the same learner (round 4 moved one default and not the other)."""
+    import inspect
+    from skill_chaining_with_graphs_amd.core import ScgContext
+    ctx_d = {k: v.default for k, v in inspect.signature(ScgContext.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
+    orc_d = {k: v.default for k, v in inspect.signature(oracle_mod.Oracle.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
+    for k in ("gamma", "alpha", "epsilon", "r_option_success", "max_episode_steps", "max_option_steps", "update_count_floor", "reoffer_period"):
+        assert ctx_d[k] == orc_d[k], (k, ctx_d[k], orc_d[k])
