@@ -26,7 +26,7 @@ def make_pair(map_name, n_envs, n_options=0, seed=0, env_id_base=0, enabled_mask
     m = scg.load_map(map_name)
     kw = dict(HP)
     kw.update(hp)
-    ctx = ScgContext(n_envs, n_options, m, device=0, seed=seed, env_id_base=env_id_base, block_envs=_BLOCK_ENVS, **kw)
+    ctx = ScgContext(n_envs, n_options, m, device=0, seed=seed, env_id_base=env_id_base, block_envs=_BLOCK_ENVS or 256, **kw)      # (explicit: the oracle pairing is per geometry)
     assert ctx.block_envs == (_BLOCK_ENVS or 256) == sc_oracle.lib().sco_block_envs()
     orc = sc_oracle.Oracle(m, SCALE, n_envs=n_envs, n_options=n_options, seed=seed, env_id_base=env_id_base,
                            enabled_mask=enabled_mask, n_threads=8, **kw)
