@@ -68,7 +68,7 @@ except (OSError, ValueError):
     pass
 
 
-TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")      # newest first
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")      # newest first
 
 
 def measured_traffic(envs_per_gpu, n_options):
