@@ -1171,12 +1171,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
         if (hipMemset(c->d_cnts, 0, (size_t)c->nblk * c->n_vf * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_G, 0, (size_t)c->n_vf * NACT * NF * sizeof(float)) != hipSuccess) { st = SCG_ERR_HIP; break; }
         if (hipMemset(c->d_nk, 0, MAX_VF * sizeof(int32_t)) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&td_kernel<MODE_FUSED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&td_kernel<MODE_TRANS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) { st = SCG_ERR_HIP; break; }
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&td_kernel<MODE_QVAL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) { st = SCG_ERR_HIP; break; }
+        // (the step kernel's LDS — 160 KB, one workgroup per CU — is static: no dynamic-LDS attribute to raise)
     } while (0);
     if (st != SCG_OK) {
         snprintf(g_err, 256, "scg_create: device allocation/setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1384,7 +1379,7 @@ int scg_step(scg_ctx *c, float *x, float *y, float *vx, float *vy, int32_t *opti
         c->prof_used += 2;
         SCG_HIP(c, hipEventRecord(ev0, s));
     }
-    hipLaunchKernelGGL(td_kernel<MODE_FUSED>, dim3(c->nblk), dim3(THREADS), LDS_BYTES, s, A);
+    hipLaunchKernelGGL(td_kernel<MODE_FUSED>, dim3(c->nblk), dim3(THREADS), 0, s, A);
     SCG_HIP(c, hipGetLastError());
     if (ev1) SCG_HIP(c, hipEventRecord(ev1, s));
     // results reach the caller's arrays through the commit workgroups of the reduce launch (or a commit launch)
@@ -1636,7 +1631,7 @@ int scg_q_values(scg_ctx *c, int32_t n, const float *x, const float *y, const fl
     A.x = const_cast<float *>(x); A.y = const_cast<float *>(y);
     A.vx = const_cast<float *>(vx); A.vy = const_cast<float *>(vy);
     A.qcache = q; A.W = Wk; A.n = n; A.k_lo = 0; A.k_hi = 0; A.cnts = nullptr; A.learn = 0;
-    hipLaunchKernelGGL(td_kernel<MODE_QVAL>, dim3((n + BLOCK_ENVS - 1) / BLOCK_ENVS), dim3(THREADS), LDS_BYTES,
+    hipLaunchKernelGGL(td_kernel<MODE_QVAL>, dim3((n + BLOCK_ENVS - 1) / BLOCK_ENVS), dim3(THREADS), 0,
                        reinterpret_cast<hipStream_t>(stream), A);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
@@ -1664,7 +1659,7 @@ int scg_q_update(scg_ctx *c, int32_t n, int32_t k, const float *x, const float *
         A.action = const_cast<uint8_t *>(action); A.reward = const_cast<float *>(r); A.cont_in = cont;
         A.xn = xn; A.yn = yn; A.vxn = vxn; A.vyn = vyn;
         A.W = W; A.n = n; A.k_lo = k; A.k_hi = k; A.learn = 1;
-        hipLaunchKernelGGL(td_kernel<MODE_TRANS>, dim3(nblk), dim3(THREADS), LDS_BYTES, s, A);
+        hipLaunchKernelGGL(td_kernel<MODE_TRANS>, dim3(nblk), dim3(THREADS), 0, s, A);
         SCG_HIP(c, hipGetLastError());
     }
     return launch_reduce(c, W, (flags & SCG_STEP_APPLY) ? 1u : 0u, nblk, s);

@@ -212,7 +212,9 @@ __device__ __attribute__((noinline)) void stage_w_cold(const float *Wk, float *s
 
 template <int MODE>
 __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // STATIC LDS: its addresses are compile-time literals. As dynamic LDS (extern __shared__[]) every address was base symbol + offset
+    // — an s_add the compiler hoisted out of the pass loop and parked in spilled SGPRs (109 of them, 172 SGPR spills; 126 now): +0.65 %
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     float *s_R = reinterpret_cast<float *>(smem + OFF_R);
     float *s_s = s_R + R_S;                                             // [8][B]: s then sn   (region R, phases P and Z)
     float *s_edges = s_R + R_EDGES;                                     // [n_edges][8]        (region R, phase P)

@@ -63,8 +63,8 @@ def test_traffic_files_are_consistent_with_the_pmc_summary():
 
 def test_bench_reads_the_newest_traffic_file():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'TRAFFIC_FILES = ("r04_traffic.json"' in src
-    assert os.path.exists(os.path.join(ROOT, "profiles", "r04_traffic.json"))
+    assert 'TRAFFIC_FILES = ("r05_traffic.json"' in src
+    assert os.path.exists(os.path.join(ROOT, "profiles", "r05_traffic.json"))
 
 
 def test_round_4_lines_carry_the_extra_measurements():
