@@ -178,6 +178,14 @@ __device__ __forceinline__ f4v zero4() {
     return (f4v){z, z, z, z};
 }
 
+// ... and the same for the integer zeros the list offsets start from: two of them, paired, were hoisted out of the pass loop, spilled before
+// E and reloaded once per unit inside E's unit loop (2 MB of scratch writes per launch)
+__device__ __forceinline__ int zero_i() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
 // W_k -> LDS in A-operand order, OUT OF LINE, for the in-pass staging (single-VF passes, steps without helper waves): that path is cold,
 // and inlined into the pass loop its sixteen-byte temporaries took part in the register allocation of the loop's hot stretches — 28 spill /
 // reload sites at pass level (16 MB of scratch writes per launch) instead of 2 (round 5).
@@ -1109,19 +1117,19 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         if ((unsigned)lw < (unsigned)LIST_WAVES) {
             const uint64_t below = (1ull << lane) - 1ull;
             if (eo) {
-                int off = 0;
+                int off = zero_i();
                 for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16 + 10 + on_me];
                 const uint64_t mine = on_me == 1 ? me[1] : on_me == 2 ? me[2] : on_me == 3 ? me[3] : on_me == 4 ? me[4] : me[5];
                 const int eb = on_me == 1 ? eo_base[1] : on_me == 2 ? eo_base[2] : on_me == 3 ? eo_base[3] : on_me == 4 ? eo_base[4] : eo_base[5];
                 s_elist[eb + off + __popcll(mine & below)] = (uint16_t)ft;
             }
             if (cmp) {
-                int off = 0;
+                int off = zero_i();
                 for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16];
                 s_elist[off + __popcll(mb[0] & below)] = (uint16_t)ft;
             }
             if (up && !u1_done) {
-                int off = 0;
+                int off = zero_i();
                 const uint64_t mine = at == 0 ? mb[1] : at == 1 ? mb[2] : at == 2 ? mb[3] : at == 3 ? mb[4] : mb[5];
                 for (int w2 = 0; w2 < lw; ++w2) off += s_misc[M_CNT + w2 * 16 + 1 + at];
                 s_ulist[sel5(run_off, at) + off + __popcll(mine & below)] = (uint16_t)ft;

@@ -123,16 +123,21 @@ def test_quarter_million_envs_single_gpu():
     assert opt.min() >= -NOPT and opt.max() <= NOPT and len(np.unique(opt)) >= 3      # (-k: inside I_k, staying out of option k)
 
 
-def test_more_than_256_workgroups_bit_exact():
+def test_the_headline_batch_learn_on_bit_exact():
+    """The exact batch of the bench line — 65 536 envs, root + 5 options, learn on, one workgroup per CU — compared with the oracle directly
+    (it was covered only through the 70 000-env case and through properties), eight step-batches."""
+    test_more_than_256_workgroups_bit_exact(n=65536, steps=8, seed=11)
+
+
+def test_more_than_256_workgroups_bit_exact(n=70000, steps=3, seed=8):
     """70 000 envs = 274 workgroups = 18 first-level segments: the reduce launch needs a second round of
     segments and the row placement a second stride over the count table — bit-exact against the oracle."""
-    n, steps = 70000, 3
     import skill_chaining_with_graphs_amd as scg
     m0 = scg.load_map("pinball_simple")
     rng = np.random.default_rng(21)
     pos = m0.sample_free(n, rng)
     v = rng.uniform(-1, 1, (2, n)).astype(np.float32)
-    ctx, orc, m = make_pair("pinball_simple", n, n_options=NOPT, seed=8, enabled_mask=MASK, max_episode_steps=40)
+    ctx, orc, m = make_pair("pinball_simple", n, n_options=NOPT, seed=seed, enabled_mask=MASK, max_episode_steps=40)
     st_o = sc_oracle.new_state(n, m)
     st_o["x"][:], st_o["y"][:], st_o["vx"][:], st_o["vy"][:] = pos[:, 0], pos[:, 1], v[0], v[1]
     st_o["ep_steps"][:] = rng.integers(0, 39, n)
