@@ -314,7 +314,11 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
     // a workgroup of this step gave up (uniform): the caller's arrays and the env order keep what the previous step left. The flag is
     // FETCHED here and looked at where the first result would be written: a test up front put one more dependent round trip in front
     // of everything the row does (+1.9 us per step-batch)
-    const int step_failed = R.fail_flag ? *R.fail_flag : 0;
+    // (read through a per-lane zero offset: as a wave-uniform load the compiler turns it into a scalar at once — global_load, s_waitcnt
+    //  vmcnt(0), v_readfirstlane — which is the up-front test again)
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const int step_failed = R.fail_flag[zoff];              // (never null: the context's flag word)
     const bool act = wv < 4 && row < R.nrow;
     const int e = row * 256 + wv * 64 + lane;
     const bool ok = act && e < R.n;
@@ -423,7 +427,7 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 // its 16 waves each sum one segment's slabs, T_s = ((P_16s + P_16s+1) + ...) over the non-empty blocks with all
 // 16 loads in flight, park T_s in LDS, and wave 0 adds the non-empty segments in order, G = ((T_0 + T_1) + ...)
 // — SPEC §5's two levels in one launch.
-__global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R) {
+__global__ __launch_bounds__(RED_THREADS, 8) void reduce_kernel(const ReduceArgs R) {
     __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
     __shared__ int s_cnt[RED_WAVES * RED_SPW];
     __shared__ int s_x[4][40];         // the commit rows' exchange area
@@ -447,15 +451,9 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
     const int nseg = (R.nblk + SEG - 1) / SEG;
     float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int nk = 0;
-    // wave 0 applies the update at the end: fetch its W and scale columns now, under the slab loads
-    float4 *wp = reinterpret_cast<float4 *>(R.W) + (size_t)k * RED_COLS + (live ? i4 : 0);
+    // wave 0 applies the update at the end: its W and scale columns are fetched under the last round's barrier
     float4 w_old = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sc = w_old;
     int step_failed = 0;
-    if (wave == 0 && R.apply) {
-        step_failed = R.fail_flag ? *R.fail_flag : 0;      // (fetched with the weights; looked at where they would be written)
-        w_old = *wp;
-        sc = *reinterpret_cast<const float4 *>(R.scale + ((live ? i4 : 0) * 4) % NF);     // NF % 4 == 0: no row straddling
-    }
     // A round = RED_SPW segments per wave (32 segments = 512 blocks in all at RED_SPW = 2: the bench size in ONE round): the
     // counts of all of a wave's segments are read first, then segment after segment its <= 16 slabs with all loads in flight,
     // and one barrier pair per round (round 2: a round was one segment per wave — two dependent count -> slab round trips and
@@ -480,22 +478,35 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
                 // vector offset = the lane's column
                 const __amdgpu_buffer_rsrc_t seg = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<char *>(slab_k + (size_t)b0 * slab_stride), 0, 0x7fffffff, 0x00020000);
-                u4v v[SEG];
+                // (two batches of eight: with all sixteen slabs in flight the kernel needed 101 VGPRs — one 16-wave workgroup per CU, and
+                //  the launch's 448 workgroups took two rounds; the sum runs in block order either way)
 #pragma unroll
-                for (int u = 0; u < SEG; ++u) {
-                    v[u] = (u4v){0u, 0u, 0u, 0u};
-                    if ((mask >> u) & 1u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(seg, (int)col_off, (int)(u * (unsigned)slab_stride), 0);
-                }
+                for (int h = 0; h < SEG; h += 8) {
+                    if (!((mask >> h) & 0xffu)) continue;
+                    u4v v[8];
 #pragma unroll
-                for (int u = 0; u < SEG; ++u) {
-                    if ((mask >> u) & 1u) {
-                        T.x = T.x + __uint_as_float(v[u][0]); T.y = T.y + __uint_as_float(v[u][1]);
-                        T.z = T.z + __uint_as_float(v[u][2]); T.w = T.w + __uint_as_float(v[u][3]);
+                    for (int u = 0; u < 8; ++u) {
+                        v[u] = (u4v){0u, 0u, 0u, 0u};
+                        if ((mask >> (h + u)) & 1u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(seg, (int)col_off, (int)((h + u) * (unsigned)slab_stride), 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if ((mask >> (h + u)) & 1u) {
+                            T.x = T.x + __uint_as_float(v[u][0]); T.y = T.y + __uint_as_float(v[u][1]);
+                            T.z = T.z + __uint_as_float(v[u][2]); T.w = T.w + __uint_as_float(v[u][3]);
+                        }
                     }
                 }
             }
             s_T[j * RED_WAVES + wave][lane] = T;
             if (lane == 0) s_cnt[j * RED_WAVES + wave] = c;
+        }
+        if (wave == 0 && R.apply && sg0 + RED_WAVES * RED_SPW >= nseg) {      // last round: under the barrier and the second-level sum
+            step_failed = *R.fail_flag;                         // (fetched with the weights; looked at where they would be written)
+            int col = live ? i4 : 0;
+            asm volatile("" : "+v"(col));                      // (addresses made HERE: hoisted to the top of the kernel they are spilled too)
+            w_old = reinterpret_cast<const float4 *>(R.W)[(size_t)k * RED_COLS + col];      // (not at the top of the kernel: held across the slab loads they were
+            sc = *reinterpret_cast<const float4 *>(R.scale + (col * 4) % NF);     //  eight more registers — spilled at 64 VGPRs; NF % 4 == 0: no row straddling)
         }
         __syncthreads();
         if (wave == 0) {
@@ -523,7 +534,9 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const ReduceArgs R)
         float4 w = w_old;
         w.x = fmaf(step * sc.x, S.x, w.x); w.y = fmaf(step * sc.y, S.y, w.y);
         w.z = fmaf(step * sc.z, S.z, w.z); w.w = fmaf(step * sc.w, S.w, w.w);
-        *wp = w;
+        int col = i4;
+        asm volatile("" : "+v"(col));
+        reinterpret_cast<float4 *>(R.W)[(size_t)k * RED_COLS + col] = w;
     }
 }
 
