@@ -431,9 +431,10 @@ __global__ __launch_bounds__(RED_THREADS, 8) void reduce_kernel(const ReduceArgs
     __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
     __shared__ int s_cnt[RED_WAVES * RED_SPW];
     __shared__ int s_x[4][40];         // the commit rows' exchange area
-    // trailing workgroups (blockIdx.y >= n_vf): one env row each — commit + next order
-    const int k = (int)blockIdx.y < R.n_vf ? (int)blockIdx.y : -1;
-    const int rowy = (int)blockIdx.y - R.n_vf;
+    // leading workgroups (blockIdx.y < gridDim.y - n_vf): one env row each — commit + next order
+    const int sy_rows = (int)gridDim.y - R.n_vf;             // the commit rows come FIRST in dispatch order (theirs is the longer chain)
+    const int k = (int)blockIdx.y >= sy_rows ? (int)blockIdx.y - sy_rows : -1;
+    const int rowy = (int)blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (k < 0) {
         const int row = rowy * (int)gridDim.x + blockIdx.x;                 // one row per workgroup (waves 0..3): a row
