@@ -427,7 +427,11 @@ __device__ __forceinline__ void commit_and_place_row(const ReduceArgs &R, int ro
 // its 16 waves each sum one segment's slabs, T_s = ((P_16s + P_16s+1) + ...) over the non-empty blocks with all
 // 16 loads in flight, park T_s in LDS, and wave 0 adds the non-empty segments in order, G = ((T_0 + T_1) + ...)
 // — SPEC §5's two levels in one launch.
-__global__ __launch_bounds__(RED_THREADS, 8) void reduce_kernel(const ReduceArgs R) {
+// BATCH = slab loads in flight per wave: 16 (101 VGPRs, one 16-wave workgroup per CU: one memory round trip per segment — for launches
+// whose workgroups fit the chip in one round anyway) or 8 (64 VGPRs, two workgroups per CU: the bench size's 448 workgroups are resident
+// together instead of in 1.75 rounds). The sum runs in block order either way: same bits.
+template <int BATCH>
+__global__ __launch_bounds__(RED_THREADS, BATCH == 16 ? 4 : 8) void reduce_kernel(const ReduceArgs R) {
     __shared__ float4 s_T[RED_WAVES * RED_SPW][64];
     __shared__ int s_cnt[RED_WAVES * RED_SPW];
     __shared__ int s_x[4][40];         // the commit rows' exchange area
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(RED_THREADS, 8) void reduce_kernel(const ReduceArgs
 #pragma unroll
         for (int j = 0; j < RED_SPW; ++j) {
             const int bl = (sg0 + j * RED_WAVES + wave) * SEG + lane;
-            cs[j] = (lane < SEG && bl < R.nblk) ? R.cnts[(size_t)bl * R.n_vf + k] : 0;
+            cs[j] = (lane < SEG && bl < R.nblk) ? R.cnts[(unsigned)(bl * R.n_vf + k)] : 0;      // (32-bit index: nblk * n_vf is small; the 64-bit form was hoisted and spilled)
         }
 #pragma unroll
         for (int j = 0; j < RED_SPW; ++j) {
@@ -479,19 +483,17 @@ __global__ __launch_bounds__(RED_THREADS, 8) void reduce_kernel(const ReduceArgs
                 // vector offset = the lane's column
                 const __amdgpu_buffer_rsrc_t seg = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<char *>(slab_k + (size_t)b0 * slab_stride), 0, 0x7fffffff, 0x00020000);
-                // (two batches of eight: with all sixteen slabs in flight the kernel needed 101 VGPRs — one 16-wave workgroup per CU, and
-                //  the launch's 448 workgroups took two rounds; the sum runs in block order either way)
 #pragma unroll
-                for (int h = 0; h < SEG; h += 8) {
-                    if (!((mask >> h) & 0xffu)) continue;
-                    u4v v[8];
+                for (int h = 0; h < SEG; h += BATCH) {
+                    if (!((mask >> h) & ((1u << BATCH) - 1u))) continue;
+                    u4v v[BATCH];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < BATCH; ++u) {
                         v[u] = (u4v){0u, 0u, 0u, 0u};
                         if ((mask >> (h + u)) & 1u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(seg, (int)col_off, (int)((h + u) * (unsigned)slab_stride), 0);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < BATCH; ++u) {
                         if ((mask >> (h + u)) & 1u) {
                             T.x = T.x + __uint_as_float(v[u][0]); T.y = T.y + __uint_as_float(v[u][1]);
                             T.z = T.z + __uint_as_float(v[u][2]); T.w = T.w + __uint_as_float(v[u][3]);
@@ -959,6 +961,7 @@ struct scg_ctx {
     scg_config cfg;
     int n_vf;
     int nblk;
+    int n_cu;                      // compute units of the device (picks the reduce launch's form)
     bool have_map;
     MapScalars ms;
     float *d_edges, *d_starts, *d_scale;
@@ -1154,6 +1157,7 @@ int scg_create(scg_ctx **out, const scg_config *cfg) {
     c->cfg = *cfg;
     c->n_vf = cfg->n_options + 1;
     c->nblk = (cfg->n_envs + BLOCK_ENVS - 1) / BLOCK_ENVS;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
     int st = SCG_OK;
     DeviceGuard dev_guard_(cfg->device);
     do {
@@ -1320,7 +1324,10 @@ static int launch_reduce(scg_ctx *c, float *W, uint32_t apply, int nblk, hipStre
         return SCG_OK;
     }
     const int sy = (nrow + RED_NCOL - 1) / RED_NCOL;
-    hipLaunchKernelGGL(reduce_kernel, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
+    if (RED_NCOL * (c->n_vf + sy) <= c->n_cu)           // fits the chip at one workgroup per CU: all sixteen slabs of a segment in flight
+        hipLaunchKernelGGL(reduce_kernel<16>, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
+    else
+        hipLaunchKernelGGL(reduce_kernel<8>, dim3(RED_NCOL, c->n_vf + sy), dim3(RED_THREADS), 0, s, R);
     SCG_HIP(c, hipGetLastError());
     return SCG_OK;
 }
