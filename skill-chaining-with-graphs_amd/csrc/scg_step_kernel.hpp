@@ -1375,37 +1375,69 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             const float *pb0 = ctab + n16 * USX + 2 * g + 2 * so, *pb1 = pb0 + 16 * USX,
                         *pb2 = ctab + min(32 + n16, 35) * USX + 2 * g + 2 * so;
             const int nvalid = j_nB - 4 * g0;                                    // B items of the run still real from group g0 on
-            for (int gi = 0; gi < ngrp; ++gi) {
-                const float2 a2 = *reinterpret_cast<const float2 *>(paA + 8 * gi);
-                float2 c0 = *reinterpret_cast<const float2 *>(pb0 + 8 * gi), c1 = *reinterpret_cast<const float2 *>(pb1 + 8 * gi),
-                       c2 = *reinterpret_cast<const float2 *>(pb2 + 8 * gi);
-                accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, a2.x, accU[0][0], 0, 0, 0);
-                accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, a2.x, accU[0][1], 0, 0, 0);
-#ifndef SCG_DIAG_FREE_BORDER
-                accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, a2.x, accU[0][2], 0, 0, 0);
-#endif
-                accU[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, a2.y, accU[0][0], 0, 0, 0);
-                accU[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, a2.y, accU[0][1], 0, 0, 0);
-#ifndef SCG_DIAG_FREE_BORDER
-                accU[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, a2.y, accU[0][2], 0, 0, 0);
-#endif
-                if (gi < ngrpB) {
-                    const float2 b2 = *reinterpret_cast<const float2 *>(paB + 8 * gi);
-                    if (4 * gi + 4 > nvalid && 4 * gi + g >= nvalid) {            // null item of B: both operands +0 (SPEC §5)
-                        c0 = make_float2(0.0f, 0.0f); c1 = c0; c2 = c0;
-                    }
-                    accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, b2.x, accU[1][0], 0, 0, 0);
-                    accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, b2.x, accU[1][1], 0, 0, 0);
-#ifndef SCG_DIAG_FREE_BORDER
-                    accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, b2.x, accU[1][2], 0, 0, 0);
-#endif
-                    accU[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, b2.y, accU[1][0], 0, 0, 0);
-                    accU[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, b2.y, accU[1][1], 0, 0, 0);
-#ifndef SCG_DIAG_FREE_BORDER
-                    accU[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, b2.y, accU[1][2], 0, 0, 0);
-#endif
+            // The no-op is 70-80 % of the items: its three waves walk ~24 groups per chunk, alone on their SIMDs (the other waves are
+            // through in a tenth of the time and wait at the barrier), so nothing hides the operands' LDS round trip — 110 of 300 ticks per
+            // group (tools/u2_loop_probe.hip). Hence: straight-line loops (the groups that carry items of B — the one group that can hold
+            // null items peeled off —, then the rest), two groups per iteration on two operand sets, the NEXT group's operands fetched
+            // before this group's products are issued. The fetches are inline asm (the compiler undoes a source-level rotation) and name
+            // an accumulator only to pin their place relative to the MFMAs; a fetch past the run's end reads inside the chunk tables.
+#define U2_LDS(P) ((unsigned)(size_t)(const __attribute__((address_space(3))) void *)(P))
+            unsigned aP = U2_LDS(paA), aQ = U2_LDS(paB), a0 = U2_LDS(pb0), a1 = U2_LDS(pb1), a2_ = U2_LDS(pb2);
+            f4v x0 = accU[0][0], x1 = accU[0][1], x2 = accU[0][2], y0 = accU[1][0], y1 = accU[1][1], y2 = accU[1][2];
+            float2 p, c0, c1, c2, q, P2, C0, C1, C2, Q2;                        // two operand sets (P operand, three C operands, B's P operand)
+#define U2_FETCH_AB(p, c0, c1, c2, q, OFF) asm volatile("ds_read_b64 %0, %6 offset:" #OFF "\n\tds_read_b64 %1, %7 offset:" #OFF "\n\tds_read_b64 %2, %8 offset:" #OFF \
+                "\n\tds_read_b64 %3, %9 offset:" #OFF "\n\tds_read_b64 %4, %10 offset:" #OFF : "=&v"(p), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(q), "+v"(x0) : "v"(aP), "v"(a0), "v"(a1), "v"(a2_), "v"(aQ))
+#define U2_FETCH_A(p, c0, c1, c2, OFF) asm volatile("ds_read_b64 %0, %5 offset:" #OFF "\n\tds_read_b64 %1, %6 offset:" #OFF "\n\tds_read_b64 %2, %7 offset:" #OFF \
+                "\n\tds_read_b64 %3, %8 offset:" #OFF : "=&v"(p), "=&v"(c0), "=&v"(c1), "=&v"(c2), "+v"(x0) : "v"(aP), "v"(a0), "v"(a1), "v"(a2_))
+#define U2_LANDED_AB(p, c0, c1, c2, q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(q), "+v"(x2), "+v"(y2))
+#define U2_LANDED_A(p, c0, c1, c2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(x2))
+#define U2_SIX(X0, X1, X2, p, c0, c1, c2) X0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, p.x, X0, 0, 0, 0); X1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, p.x, X1, 0, 0, 0); \
+                X2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, p.x, X2, 0, 0, 0); X0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, p.y, X0, 0, 0, 0); \
+                X1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, p.y, X1, 0, 0, 0); X2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, p.y, X2, 0, 0, 0)
+#define U2_BUMP(N) aP += 32 * (N); aQ += 32 * (N); a0 += 32 * (N); a1 += 32 * (N); a2_ += 32 * (N)
+            const int nBfull = ngrpB > 0 && nvalid < 4 * ngrpB ? ngrpB - 1 : ngrpB;      // B's groups of four REAL items (only its last group can hold null items)
+            int gi = 0;
+            if (nBfull > 0) {
+                U2_FETCH_AB(p, c0, c1, c2, q, 0); U2_LANDED_AB(p, c0, c1, c2, q);
+                for (; gi + 1 < nBfull; gi += 2) {
+                    U2_FETCH_AB(P2, C0, C1, C2, Q2, 32);
+                    U2_SIX(x0, x1, x2, p, c0, c1, c2); U2_SIX(y0, y1, y2, q, c0, c1, c2);
+                    U2_LANDED_AB(P2, C0, C1, C2, Q2);
+                    U2_FETCH_AB(p, c0, c1, c2, q, 64);
+                    U2_SIX(x0, x1, x2, P2, C0, C1, C2); U2_SIX(y0, y1, y2, Q2, C0, C1, C2);
+                    U2_LANDED_AB(p, c0, c1, c2, q);
+                    U2_BUMP(2);
                 }
+                if (gi < nBfull) { U2_SIX(x0, x1, x2, p, c0, c1, c2); U2_SIX(y0, y1, y2, q, c0, c1, c2); ++gi; U2_BUMP(1); }
             }
+            if (gi < ngrpB) {                                                    // B's last group with null items: both operands +0 (SPEC §5)
+                U2_FETCH_AB(p, c0, c1, c2, q, 0); U2_LANDED_AB(p, c0, c1, c2, q);
+                U2_SIX(x0, x1, x2, p, c0, c1, c2);
+                if (4 * gi + g >= nvalid) { c0 = make_float2(0.0f, 0.0f); c1 = c0; c2 = c0; }
+                U2_SIX(y0, y1, y2, q, c0, c1, c2);
+                ++gi; U2_BUMP(1);
+            }
+            if (gi < ngrp) {
+                U2_FETCH_A(p, c0, c1, c2, 0); U2_LANDED_A(p, c0, c1, c2);
+                for (; gi + 1 < ngrp; gi += 2) {
+                    U2_FETCH_A(P2, C0, C1, C2, 32);
+                    U2_SIX(x0, x1, x2, p, c0, c1, c2);
+                    U2_LANDED_A(P2, C0, C1, C2);
+                    U2_FETCH_A(p, c0, c1, c2, 64);
+                    U2_SIX(x0, x1, x2, P2, C0, C1, C2);
+                    U2_LANDED_A(p, c0, c1, c2);
+                    U2_BUMP(2);
+                }
+                if (gi < ngrp) { U2_SIX(x0, x1, x2, p, c0, c1, c2); }
+            }
+            accU[0][0] = x0; accU[0][1] = x1; accU[0][2] = x2; accU[1][0] = y0; accU[1][1] = y1; accU[1][2] = y2;
+#undef U2_LDS
+#undef U2_FETCH_AB
+#undef U2_FETCH_A
+#undef U2_LANDED_AB
+#undef U2_LANDED_A
+#undef U2_SIX
+#undef U2_BUMP
         };
         for (int ch = 0; ch < nch; ++ch) {
             if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
