@@ -59,6 +59,10 @@ __global__ __launch_bounds__(1024, 4) void probe(float *out, unsigned long long 
             SIX(q, d0, d1, d2);
             LANDED(p, c0, c1, c2);
         }
+    } else if (VARIANT == 7) {                              // calibration: 2048 dependent v_add_f32 (the same chain runs on an idle wave inside the step kernel's U2)
+        float v = (float)lane;
+        for (int i = 0; i < 256; ++i) asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0\n\tv_add_f32 %0, %0, %0" : "+v"(v));
+        a0[0] = v;
     } else if (VARIANT == 5 || VARIANT == 6) {              // round 5's re-mapped loop: one tile, one P + one C (+ one B) operand, two (+ two) dependent MFMAs per group
         const float *paB = tab + 36 * USX + n16 * USX + 2 * g;
         for (int gi = 0; gi < ngrp; ++gi) {
@@ -109,6 +113,7 @@ int main() {
         run<4>("ping-pong operand sets, fetches in inline asm", nblk);
         run<5>("re-mapped: 9 waves, 2 reads + 2 dependent MFMAs", nblk);
         run<6>("re-mapped: 9 waves, 3 reads + 2 + 2 dependent MFMAs", nblk);
+        run<7>("calibration: 2048 dependent v_add_f32, one wave per SIMD", nblk);
         run<0, true>("the kernel's loop, the other 13 waves WAITING at a barrier", nblk);
         run<6, true>("re-mapped, 3 reads + 2 + 2, the other 7 waves WAITING", nblk);
     }
