@@ -6,11 +6,15 @@
 #include <cstdio>
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int USX = 292, NG = 24;
-template <int VARIANT, bool WAITERS>
+template <int VARIANT, bool WAITERS, bool RANDOM_DATA>
 __global__ __launch_bounds__(1024, 4) void probe(float *out, unsigned long long *cyc, int ngrp) {
     extern __shared__ float tab[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n16 = lane & 15, g = lane >> 4;
-    for (int i = tid; i < 3 * 36 * USX; i += 1024) tab[i] = 1e-3f * (float)(i % 97);
+    for (int i = tid; i < 3 * 36 * USX; i += 1024) {
+        unsigned h = (unsigned)i * 2654435761u + (unsigned)ngrp * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        tab[i] = RANDOM_DATA ? __uint_as_float((h & 0x807fffffu) | 0x3f000000u) - ((h >> 8) & 1 ? 0.75f : 0.0f)      // full mantissas, both signs, |x| < 1
+                             : 1e-3f * (float)(i % 97);
+    }
     __syncthreads();
     const bool idle = VARIANT >= 5 ? !((0x703f >> wave) & 1) : (wave < 12 || wave > 14);
     if (idle && !WAITERS) return;
@@ -90,11 +94,11 @@ __global__ __launch_bounds__(1024, 4) void probe(float *out, unsigned long long 
     out[(blockIdx.x * 1024 + tid) * 3] = a0[0] + a1[1] + a2[2];
     if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
 }
-template <int V, bool WT = false> static void run(const char *name, int nblk) {
+template <int V, bool WT = false, bool RD = false> static void run(const char *name, int nblk) {
     float *out; unsigned long long *cyc;
     hipMalloc(&out, (size_t)nblk * 1024 * 3 * 4); hipMalloc(&cyc, (size_t)nblk * 16 * 8);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<V, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 36 * USX * 4);
-    for (int r = 0; r < 3; ++r) probe<V, WT><<<nblk, 1024, 3 * 36 * USX * 4>>>(out, cyc, NG);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&probe<V, WT, RD>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 36 * USX * 4);
+    for (int r = 0; r < 3; ++r) probe<V, WT, RD><<<nblk, 1024, 3 * 36 * USX * 4>>>(out, cyc, NG);
     hipDeviceSynchronize();
     unsigned long long *h = new unsigned long long[nblk * 16];
     hipMemcpy(h, cyc, (size_t)nblk * 16 * 8, hipMemcpyDeviceToHost);
@@ -114,6 +118,9 @@ int main() {
         run<5>("re-mapped: 9 waves, 2 reads + 2 dependent MFMAs", nblk);
         run<6>("re-mapped: 9 waves, 3 reads + 2 + 2 dependent MFMAs", nblk);
         run<7>("calibration: 2048 dependent v_add_f32, one wave per SIMD", nblk);
+        run<0, false, true>("the kernel's loop, RANDOM operands (full mantissas, both signs)", nblk);
+        run<4, false, true>("ping-pong, RANDOM operands", nblk);
+        run<1, false, true>("operands in registers, RANDOM operands", nblk);
         run<0, true>("the kernel's loop, the other 13 waves WAITING at a barrier", nblk);
         run<6, true>("re-mapped, 3 reads + 2 + 2, the other 7 waves WAITING", nblk);
     }
