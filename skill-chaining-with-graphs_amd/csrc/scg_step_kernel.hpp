@@ -1378,66 +1378,77 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             // The no-op is 70-80 % of the items: its three waves walk ~24 groups per chunk, alone on their SIMDs (the other waves are
             // through in a tenth of the time and wait at the barrier), so nothing hides the operands' LDS round trip — 110 of 300 ticks per
             // group (tools/u2_loop_probe.hip). Hence: straight-line loops (the groups that carry items of B — the one group that can hold
-            // null items peeled off —, then the rest), two groups per iteration on two operand sets, the NEXT group's operands fetched
-            // before this group's products are issued. The fetches are inline asm (the compiler undoes a source-level rotation) and name
-            // an accumulator only to pin their place relative to the MFMAs; a fetch past the run's end reads inside the chunk tables.
+            // null items peeled off —, then the rest) on two operand sets, the NEXT group's operands fetched before this group's products
+            // are issued; a fetch past the run's end reads inside the chunk tables.
+            // The whole walk is ONE asm statement on fixed operand registers (v108..v127), accumulators tied (vdst = srcC). As builtins the
+            // register allocator kept two copies of every accumulator round the loops: per iteration of 12 products `s_nop 6` (the copies
+            // read MFMA results: the pipe drains), 10-18 v_mov_b64 on the pipe the products use and two taken branches — the 1.35-1.8x
+            // between this loop in the kernel and in the probe (profiles/r05_u2_anatomy.txt item 5; found by reading the ISA). The compiler's
+            // hazard recognizer does not see inside asm: dependent products are three apart on one opcode and one vdst (what the compiler
+            // emits itself), operands are re-fetched only behind the products that read them (an LDS return is > 64 cycles away, sources are
+            // read at issue), and the wait states a VALU / VMEM read of a result needs are issued once, at the end.
 #define U2_LDS(P) ((unsigned)(size_t)(const __attribute__((address_space(3))) void *)(P))
             unsigned aP = U2_LDS(paA), aQ = U2_LDS(paB), a0 = U2_LDS(pb0), a1 = U2_LDS(pb1), a2_ = U2_LDS(pb2);
             f4v x0 = accU[0][0], x1 = accU[0][1], x2 = accU[0][2], y0 = accU[1][0], y1 = accU[1][1], y2 = accU[1][2];
-            float2 p, c0, c1, c2, q, P2, C0, C1, C2, Q2;                        // two operand sets (P operand, three C operands, B's P operand)
-#define U2_FETCH_AB(p, c0, c1, c2, q, OFF) asm volatile("ds_read_b64 %0, %6 offset:" #OFF "\n\tds_read_b64 %1, %7 offset:" #OFF "\n\tds_read_b64 %2, %8 offset:" #OFF \
-                "\n\tds_read_b64 %3, %9 offset:" #OFF "\n\tds_read_b64 %4, %10 offset:" #OFF : "=&v"(p), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(q), "+v"(x0) : "v"(aP), "v"(a0), "v"(a1), "v"(a2_), "v"(aQ))
-#define U2_FETCH_A(p, c0, c1, c2, OFF) asm volatile("ds_read_b64 %0, %5 offset:" #OFF "\n\tds_read_b64 %1, %6 offset:" #OFF "\n\tds_read_b64 %2, %7 offset:" #OFF \
-                "\n\tds_read_b64 %3, %8 offset:" #OFF : "=&v"(p), "=&v"(c0), "=&v"(c1), "=&v"(c2), "+v"(x0) : "v"(aP), "v"(a0), "v"(a1), "v"(a2_))
-#define U2_LANDED_AB(p, c0, c1, c2, q) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(q), "+v"(x2), "+v"(y2))
-#define U2_LANDED_A(p, c0, c1, c2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(x2))
-#define U2_SIX(X0, X1, X2, p, c0, c1, c2) X0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.x, p.x, X0, 0, 0, 0); X1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.x, p.x, X1, 0, 0, 0); \
-                X2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.x, p.x, X2, 0, 0, 0); X0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.y, p.y, X0, 0, 0, 0); \
-                X1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.y, p.y, X1, 0, 0, 0); X2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c2.y, p.y, X2, 0, 0, 0)
-#define U2_BUMP(N) aP += 32 * (N); aQ += 32 * (N); a0 += 32 * (N); a1 += 32 * (N); a2_ += 32 * (N)
             const int nBfull = ngrpB > 0 && nvalid < 4 * ngrpB ? ngrpB - 1 : ngrpB;      // B's groups of four REAL items (only its last group can hold null items)
-            int gi = 0;
-            if (nBfull > 0) {
-                U2_FETCH_AB(p, c0, c1, c2, q, 0); U2_LANDED_AB(p, c0, c1, c2, q);
-                for (; gi + 1 < nBfull; gi += 2) {
-                    U2_FETCH_AB(P2, C0, C1, C2, Q2, 32);
-                    U2_SIX(x0, x1, x2, p, c0, c1, c2); U2_SIX(y0, y1, y2, q, c0, c1, c2);
-                    U2_LANDED_AB(P2, C0, C1, C2, Q2);
-                    U2_FETCH_AB(p, c0, c1, c2, q, 64);
-                    U2_SIX(x0, x1, x2, P2, C0, C1, C2); U2_SIX(y0, y1, y2, Q2, C0, C1, C2);
-                    U2_LANDED_AB(p, c0, c1, c2, q);
-                    U2_BUMP(2);
-                }
-                if (gi < nBfull) { U2_SIX(x0, x1, x2, p, c0, c1, c2); U2_SIX(y0, y1, y2, q, c0, c1, c2); ++gi; U2_BUMP(1); }
-            }
-            if (gi < ngrpB) {                                                    // B's last group with null items: both operands +0 (SPEC §5)
-                U2_FETCH_AB(p, c0, c1, c2, q, 0); U2_LANDED_AB(p, c0, c1, c2, q);
-                U2_SIX(x0, x1, x2, p, c0, c1, c2);
-                if (4 * gi + g >= nvalid) { c0 = make_float2(0.0f, 0.0f); c1 = c0; c2 = c0; }
-                U2_SIX(y0, y1, y2, q, c0, c1, c2);
-                ++gi; U2_BUMP(1);
-            }
-            if (gi < ngrp) {
-                U2_FETCH_A(p, c0, c1, c2, 0); U2_LANDED_A(p, c0, c1, c2);
-                for (; gi + 1 < ngrp; gi += 2) {
-                    U2_FETCH_A(P2, C0, C1, C2, 32);
-                    U2_SIX(x0, x1, x2, p, c0, c1, c2);
-                    U2_LANDED_A(P2, C0, C1, C2);
-                    U2_FETCH_A(p, c0, c1, c2, 64);
-                    U2_SIX(x0, x1, x2, P2, C0, C1, C2);
-                    U2_LANDED_A(p, c0, c1, c2);
-                    U2_BUMP(2);
-                }
-                if (gi < ngrp) { U2_SIX(x0, x1, x2, p, c0, c1, c2); }
-            }
-            accU[0][0] = x0; accU[0][1] = x1; accU[0][2] = x2; accU[1][0] = y0; accU[1][1] = y1; accU[1][2] = y2;
+            const int nAonly = ngrp - ngrpB;
+            const unsigned long long nullmask = __ballot(4 * nBfull + g >= nvalid);     // lanes whose item of B's last group is a null item: C operand +0 (SPEC §5)
+            unsigned cnt;
+            // operand set 1: P v[108:109], C0 v[110:111], C1 v[112:113], C2 v[114:115], B's P v[116:117]; set 2: v[118:119] .. v[126:127]
+#define MF(ACC, A_, B_) "v_mfma_f32_16x16x4_f32 %[" ACC "], " A_ ", " B_ ", %[" ACC "]\n\t"
+#define SX1 MF("x0", "v110", "v108") MF("x1", "v112", "v108") MF("x2", "v114", "v108") MF("x0", "v111", "v109") MF("x1", "v113", "v109") MF("x2", "v115", "v109")
+#define SY1 MF("y0", "v110", "v116") MF("y1", "v112", "v116") MF("y2", "v114", "v116") MF("y0", "v111", "v117") MF("y1", "v113", "v117") MF("y2", "v115", "v117")
+#define SX2 MF("x0", "v120", "v118") MF("x1", "v122", "v118") MF("x2", "v124", "v118") MF("x0", "v121", "v119") MF("x1", "v123", "v119") MF("x2", "v125", "v119")
+#define SY2 MF("y0", "v120", "v126") MF("y1", "v122", "v126") MF("y2", "v124", "v126") MF("y0", "v121", "v127") MF("y1", "v123", "v127") MF("y2", "v125", "v127")
+#define SYP MF("y0", "v120", "v116") MF("y1", "v122", "v116") MF("y2", "v124", "v116") MF("y0", "v121", "v117") MF("y1", "v123", "v117") MF("y2", "v125", "v117")
+#define F1A(O) "ds_read_b64 v[108:109], %[aP] offset:" O "\n\tds_read_b64 v[110:111], %[a0] offset:" O "\n\tds_read_b64 v[112:113], %[a1] offset:" O "\n\tds_read_b64 v[114:115], %[a2] offset:" O "\n\t"
+#define F2A(O) "ds_read_b64 v[118:119], %[aP] offset:" O "\n\tds_read_b64 v[120:121], %[a0] offset:" O "\n\tds_read_b64 v[122:123], %[a1] offset:" O "\n\tds_read_b64 v[124:125], %[a2] offset:" O "\n\t"
+#define F1Q(O) "ds_read_b64 v[116:117], %[aQ] offset:" O "\n\t"
+#define F2Q(O) "ds_read_b64 v[126:127], %[aQ] offset:" O "\n\t"
+#define LW "s_waitcnt lgkmcnt(0)\n\t"
+#define BUMP(N) "v_add_u32_e32 %[aP], " N ", %[aP]\n\tv_add_u32_e32 %[aQ], " N ", %[aQ]\n\tv_add_u32_e32 %[a0], " N ", %[a0]\n\tv_add_u32_e32 %[a1], " N ", %[a1]\n\tv_add_u32_e32 %[a2], " N ", %[a2]\n\t"
+#define ZC(D, S) "v_cndmask_b32_e64 " D ", " S ", 0, %[nm]\n\t"
+            asm volatile(
+                "s_cmp_eq_u32 %[nBall], 0\n\ts_cbranch_scc1 10f\n\t"
+                // ---- groups with items of both value functions: invariant — set 1 holds the landed operands of the next group
+                F1A("0") F1Q("0") LW
+                "s_lshr_b32 %[cnt], %[nB], 2\n\ts_cmp_eq_u32 %[cnt], 0\n\ts_cbranch_scc1 2f\n"
+                "1:\n\t" F2A("32") F2Q("32") SX1 SY1 LW F1A("64") F1Q("64") SX2 SY2 LW F2A("96") F2Q("96") SX1 SY1 LW F1A("128") F1Q("128") SX2 SY2 LW BUMP("0x80")
+                "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 0\n\ts_cbranch_scc1 1b\n"
+                "2:\n\ts_bitcmp1_b32 %[nB], 1\n\ts_cbranch_scc0 3f\n\t" F2A("32") F2Q("32") SX1 SY1 LW F1A("64") F1Q("64") SX2 SY2 LW BUMP("64")
+                "\n3:\n\ts_bitcmp1_b32 %[nB], 0\n\ts_cbranch_scc0 4f\n\t" SX1 SY1 F1A("32") F1Q("32") LW BUMP("32")
+                // B's last group with null items: the C operands of the null lanes are +0 for B's products only
+                "\n4:\n\ts_cmp_eq_u32 %[nBall], %[nB]\n\ts_cbranch_scc1 11f\n\t" SX1
+                ZC("v120", "v110") ZC("v121", "v111") ZC("v122", "v112") ZC("v123", "v113") ZC("v124", "v114") ZC("v125", "v115") SYP F1A("32") LW BUMP("32")
+                "s_branch 11f\n"
+                "10:\n\ts_cmp_eq_u32 %[nA], 0\n\ts_cbranch_scc1 20f\n\t" F1A("0") LW
+                // ---- the rest of the run: the block's own value function only
+                "\n11:\n\ts_lshr_b32 %[cnt], %[nA], 2\n\ts_cmp_eq_u32 %[cnt], 0\n\ts_cbranch_scc1 13f\n"
+                "12:\n\t" F2A("32") SX1 LW F1A("64") SX2 LW F2A("96") SX1 LW F1A("128") SX2 LW BUMP("0x80")
+                "s_sub_u32 %[cnt], %[cnt], 1\n\ts_cmp_lg_u32 %[cnt], 0\n\ts_cbranch_scc1 12b\n"
+                "13:\n\ts_bitcmp1_b32 %[nA], 1\n\ts_cbranch_scc0 14f\n\t" F2A("32") SX1 LW F1A("64") SX2 LW BUMP("64")
+                "\n14:\n\ts_bitcmp1_b32 %[nA], 0\n\ts_cbranch_scc0 20f\n\t" SX1
+                "\n20:\n\ts_nop 15\n\ts_nop 7"
+                : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [y0] "+v"(y0), [y1] "+v"(y1), [y2] "+v"(y2),
+                  [aP] "+v"(aP), [aQ] "+v"(aQ), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2_), [cnt] "=&s"(cnt)
+                : [nB] "s"(nBfull), [nBall] "s"(ngrpB), [nA] "s"(nAonly), [nm] "s"(nullmask)
+                : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124",
+                  "v125", "v126", "v127", "scc");
+#undef MF
+#undef SX1
+#undef SY1
+#undef SX2
+#undef SY2
+#undef SYP
+#undef F1A
+#undef F2A
+#undef F1Q
+#undef F2Q
+#undef LW
+#undef BUMP
+#undef ZC
 #undef U2_LDS
-#undef U2_FETCH_AB
-#undef U2_FETCH_A
-#undef U2_LANDED_AB
-#undef U2_LANDED_A
-#undef U2_SIX
-#undef U2_BUMP
+            accU[0][0] = x0; accU[0][1] = x1; accU[0][2] = x2; accU[1][0] = y0; accU[1][1] = y1; accU[1][2] = y2;
         };
         for (int ch = 0; ch < nch; ++ch) {
             if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
@@ -1493,6 +1504,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
         for (int i = 1; i < 8; ++i) o[lite_role * 8 + i] += lt[i] ? lt[i] - lt[0] : 0ull;
         o[lite_role * 8] += __builtin_amdgcn_s_memtime() - lt[0];                 // [0]: the wave's whole kernel
         if (lite_role == 0) { o[32] = lite_r0; o[33] = __builtin_amdgcn_s_memrealtime(); }
+    }
+    if (MODE == MODE_FUSED && A.stamps && lane == 0) {      // slots 34..41: HW_REG_HW_ID of each of the 16 waves (last launch): where the dispatcher put wave w (tools/wave_placement.py)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        reinterpret_cast<unsigned *>(A.stamps + (size_t)blockIdx.x * STAMP_SLOTS + 34)[wave] = hwid;
     }
 #endif
 #ifdef SCG_STAMPS
