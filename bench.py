@@ -87,6 +87,47 @@ def measured_traffic(envs_per_gpu, n_options):
     return None, None
 
 
+def live_traffic(envs_per_gpu, n_options, timeout_s=150):
+    """(bytes, source, raw) or None: HBM bytes per launch of the step kernel measured NOW — two child runs of this file under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes with --kernel-trace only, the program itself behind `--`),
+    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE doubled, WRITE_SIZE exact; units of KB).
+    Called before this process has touched the GPU (children of a GPU-initialised process are not allowed on the pool), never
+    under a profiler, single-GPU runs only; any failure returns None and the line falls back to the tracked static figure."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or os.environ.get("HSA_TOOLS_LIB") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None                                  # this run is itself being profiled: its process has the GPU open already
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="scg_traffic_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "30", "--warmup", "5", "--ramp", "20", "--envs-per-gpu", str(envs_per_gpu),
+                   "--options", str(n_options), "--no-cpu-baseline", "--no-extras", "--no-live-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "td_kernel<0>" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None
+            raw[ctr] = sum(per.values()) / len(per)
+            raw[ctr + "_dispatches"] = len(per)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (int((2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024),
+            "measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two child passes of this workload (30 timed step-batches each), "
+            "per launch of td_kernel<0>; gfx950 correction per MI355X_MICROARCH.md: 2 x FETCH_SIZE + WRITE_SIZE, KB", raw)
+
+
 def host_cpu_share():
     """CPUs this process can really use: the affinity mask capped by the cgroup CPU quota (a 1-GPU box of the pool shows
     256 CPUs in its mask and a quota of 16; 256 OpenMP threads inside that quota run 6x SLOWER than 16)."""
@@ -234,7 +275,14 @@ def main():
                     "(0 = max(8, steps // 8): each pair costs a few us of queue bubble — 3 us per step when every other launch is sampled)")
     ap.add_argument("--ramp", type=int, default=200, help="untimed clock-ramp step-batches before the warm-up "
                     "(a 20-step run otherwise times a cold GPU and the first step's stand-alone sort)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the tracked profile instead of two rocprofv3 counter "
+                    "passes of this workload run first (single-GPU runs; skipped anyway with --no-extras, under a profiler, or when rocprofv3 is missing)")
     args = ap.parse_args()
+
+    live = None
+    if ("WORLD_SIZE" not in os.environ and args.gpus == 1 and not args.no_live_traffic and not args.no_extras
+            and not (args.no_learn or args.diag_no_td or args.diag_fresh_sort or args.shared_weights)):
+        live = live_traffic(args.envs_per_gpu, args.options)      # BEFORE anything here touches the GPU (no torch import yet)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N`: become the launcher. Nothing in this process has touched the GPU (no torch
@@ -346,6 +394,9 @@ def main():
         units = n_local
         achieved = units * BYTES_PER_ENV_STEP / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic, traffic_source = measured_traffic(n_local, n_opt)
+        traffic_raw = None
+        if live is not None:
+            traffic, traffic_source, traffic_raw = live
         out = {
             "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -367,7 +418,7 @@ def main():
                                          "launch needs its result)"))},
             "roofline": {"bound": "hbm", "kernel": "td_kernel<MODE_FUSED>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": kern_ms, "launches": int(k_n.value),
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_counters_kb": traffic_raw, "kernel_ms": kern_ms, "launches": int(k_n.value),
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                          "note": "the fused kernel is compute- and latency-bound (f32 matrix pipe 50 % busy), not HBM-bound (SURVEY.md \u00a78d, "
                                  "DESIGN.md): see `mfma` for the binding roofline"},

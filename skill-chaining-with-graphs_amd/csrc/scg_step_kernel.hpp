@@ -73,7 +73,11 @@ constexpr int LDS_BYTES = OFF_MISC + 512;
 // on the way. Slots per block: [wave role 0..3][8 boundaries] cycles since the wave's kernel entry, [32] start and [33] end on the
 // 100 MHz wall clock (launch ramp across the chip).
 constexpr int STAMP_SLOTS = 48;
-#if SCG_STAMPS_LITE == 2      // variant: the env wave's eight boundaries lie INSIDE phase P (the other roles keep theirs)
+#if SCG_STAMPS_LITE == 3      // variant: waves 12, 13 (two of the no-op's), 0 and 3 stamp INSIDE U2 of pass 0 (tools/lite_report.py --u2)
+#define SCG_LITE(I) do { if (MODE == MODE_FUSED && lite_role >= 0 && ((I) == 0 || (I) == 7)) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SCG_LITEP(I) do { } while (0)
+#define SCG_LITEU(I) do { if (MODE == MODE_FUSED && lite_role >= 0 && pass == 0) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#elif SCG_STAMPS_LITE == 2    // variant: the env wave's eight boundaries lie INSIDE phase P (the other roles keep theirs)
 #define SCG_LITE(I) do { if (MODE == MODE_FUSED && (lite_role >= 1 || (I) == 0)) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define SCG_LITEP(I) do { if (MODE == MODE_FUSED && lite_role == 0) lt[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -83,6 +87,9 @@ constexpr int STAMP_SLOTS = 48;
 #else
 #define SCG_LITE(I) do { } while (0)
 #define SCG_LITEP(I) do { } while (0)
+#endif
+#ifndef SCG_LITEU
+#define SCG_LITEU(I) do { } while (0)
 #endif
 static_assert(BLOCK_ENVS / 8 <= 64, "eflag area");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget: one workgroup per CU");
@@ -251,7 +258,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     const int nb = min(BLOCK_ENVS, A.n - e0);
     const int N = A.n;
 #ifdef SCG_STAMPS_LITE
+#if SCG_STAMPS_LITE == 3
+    const int lite_role = wave == 12 ? 0 : wave == 13 ? 1 : wave == 0 ? 2 : wave == 3 ? 3 : -1;
+#else
     const int lite_role = wave == 0 ? 0 : wave == P_WAVES ? 1 : wave == HELPER0 ? 2 : wave == WAVES - 1 ? 3 : -1;
+#endif
     unsigned long long lt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long lite_r0 = __builtin_amdgcn_s_memrealtime();
     SCG_LITE(0);
@@ -1366,13 +1377,13 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #endif
             int gb[NACT], gc[NACT], co[NACT + 1];
             chunk_geo(ch, gb, gc, co);
-            const float *ptabA = tab, *ptabB = tab + 36 * USX, *ctab = tab + 2 * 36 * USX;
+            const float *ptabA = tab, *ctab = tab + 2 * 36 * USX;                // (PT_B lies between them)
             const int ngrp = sel5(gc, ja), g0 = sel5(gb, ja), so = sel5(co, ja);      // run ja's groups in this chunk, from group g0, at slot so
             if (ngrp <= 0) return;
             const int ngrpB = haveB ? min(max(j_GB - g0, 0), ngrp) : 0;          // ... of which B's
             const int prow = min(16 * jm + n16, 35) * USX + 2 * g + 2 * so;
-            const float *paA = ptabA + prow, *paB = ptabB + prow;
-            const float *pb0 = ctab + n16 * USX + 2 * g + 2 * so, *pb1 = pb0 + 16 * USX,
+            const float *paA = ptabA + prow;                                     // (B's P operand: the same row of ptabB = + 36 USX floats)
+            const float *pb0 = ctab + n16 * USX + 2 * g + 2 * so,                // (the second C operand: + 16 USX floats)
                         *pb2 = ctab + min(32 + n16, 35) * USX + 2 * g + 2 * so;
             const int nvalid = j_nB - 4 * g0;                                    // B items of the run still real from group g0 on
             // The no-op is 70-80 % of the items: its three waves walk ~24 groups per chunk, alone on their SIMDs (the other waves are
@@ -1388,25 +1399,25 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
             // emits itself), operands are re-fetched only behind the products that read them (an LDS return is > 64 cycles away, sources are
             // read at issue), and the wait states a VALU / VMEM read of a result needs are issued once, at the end.
 #define U2_LDS(P) ((unsigned)(size_t)(const __attribute__((address_space(3))) void *)(P))
-            unsigned aP = U2_LDS(paA), aQ = U2_LDS(paB), a0 = U2_LDS(pb0), a1 = U2_LDS(pb1), a2_ = U2_LDS(pb2);
+            unsigned aP = U2_LDS(paA), a0 = U2_LDS(pb0), a2_ = U2_LDS(pb2);          // B's P operand (paB) and the second C operand (pb1) lie at fixed offsets from these
             f4v x0 = accU[0][0], x1 = accU[0][1], x2 = accU[0][2], y0 = accU[1][0], y1 = accU[1][1], y2 = accU[1][2];
             const int nBfull = ngrpB > 0 && nvalid < 4 * ngrpB ? ngrpB - 1 : ngrpB;      // B's groups of four REAL items (only its last group can hold null items)
             const int nAonly = ngrp - ngrpB;
             const unsigned long long nullmask = __ballot(4 * nBfull + g >= nvalid);     // lanes whose item of B's last group is a null item: C operand +0 (SPEC §5)
             unsigned cnt;
-            // operand set 1: P v[108:109], C0 v[110:111], C1 v[112:113], C2 v[114:115], B's P v[116:117]; set 2: v[118:119] .. v[126:127]
+            // operand set 1: P v[100:101], C0 v[102:103], C1 v[104:105], C2 v[106:107], B's P v[108:109]; set 2: v[110:111] .. v[118:119]
 #define MF(ACC, A_, B_) "v_mfma_f32_16x16x4_f32 %[" ACC "], " A_ ", " B_ ", %[" ACC "]\n\t"
-#define SX1 MF("x0", "v110", "v108") MF("x1", "v112", "v108") MF("x2", "v114", "v108") MF("x0", "v111", "v109") MF("x1", "v113", "v109") MF("x2", "v115", "v109")
-#define SY1 MF("y0", "v110", "v116") MF("y1", "v112", "v116") MF("y2", "v114", "v116") MF("y0", "v111", "v117") MF("y1", "v113", "v117") MF("y2", "v115", "v117")
-#define SX2 MF("x0", "v120", "v118") MF("x1", "v122", "v118") MF("x2", "v124", "v118") MF("x0", "v121", "v119") MF("x1", "v123", "v119") MF("x2", "v125", "v119")
-#define SY2 MF("y0", "v120", "v126") MF("y1", "v122", "v126") MF("y2", "v124", "v126") MF("y0", "v121", "v127") MF("y1", "v123", "v127") MF("y2", "v125", "v127")
-#define SYP MF("y0", "v120", "v116") MF("y1", "v122", "v116") MF("y2", "v124", "v116") MF("y0", "v121", "v117") MF("y1", "v123", "v117") MF("y2", "v125", "v117")
-#define F1A(O) "ds_read_b64 v[108:109], %[aP] offset:" O "\n\tds_read_b64 v[110:111], %[a0] offset:" O "\n\tds_read_b64 v[112:113], %[a1] offset:" O "\n\tds_read_b64 v[114:115], %[a2] offset:" O "\n\t"
-#define F2A(O) "ds_read_b64 v[118:119], %[aP] offset:" O "\n\tds_read_b64 v[120:121], %[a0] offset:" O "\n\tds_read_b64 v[122:123], %[a1] offset:" O "\n\tds_read_b64 v[124:125], %[a2] offset:" O "\n\t"
-#define F1Q(O) "ds_read_b64 v[116:117], %[aQ] offset:" O "\n\t"
-#define F2Q(O) "ds_read_b64 v[126:127], %[aQ] offset:" O "\n\t"
+#define SX1 MF("x0", "v102", "v100") MF("x1", "v104", "v100") MF("x2", "v106", "v100") MF("x0", "v103", "v101") MF("x1", "v105", "v101") MF("x2", "v107", "v101")
+#define SY1 MF("y0", "v102", "v108") MF("y1", "v104", "v108") MF("y2", "v106", "v108") MF("y0", "v103", "v109") MF("y1", "v105", "v109") MF("y2", "v107", "v109")
+#define SX2 MF("x0", "v112", "v110") MF("x1", "v114", "v110") MF("x2", "v116", "v110") MF("x0", "v113", "v111") MF("x1", "v115", "v111") MF("x2", "v117", "v111")
+#define SY2 MF("y0", "v112", "v118") MF("y1", "v114", "v118") MF("y2", "v116", "v118") MF("y0", "v113", "v119") MF("y1", "v115", "v119") MF("y2", "v117", "v119")
+#define SYP MF("y0", "v112", "v108") MF("y1", "v114", "v108") MF("y2", "v116", "v108") MF("y0", "v113", "v109") MF("y1", "v115", "v109") MF("y2", "v117", "v109")
+#define F1A(O) "ds_read_b64 v[100:101], %[aP] offset:" O "\n\tds_read_b64 v[102:103], %[a0] offset:" O "\n\tds_read_b64 v[104:105], %[a0] offset:%[o1]+" O "\n\tds_read_b64 v[106:107], %[a2] offset:" O "\n\t"
+#define F2A(O) "ds_read_b64 v[110:111], %[aP] offset:" O "\n\tds_read_b64 v[112:113], %[a0] offset:" O "\n\tds_read_b64 v[114:115], %[a0] offset:%[o1]+" O "\n\tds_read_b64 v[116:117], %[a2] offset:" O "\n\t"
+#define F1Q(O) "ds_read_b64 v[108:109], %[aP] offset:%[oq]+" O "\n\t"
+#define F2Q(O) "ds_read_b64 v[118:119], %[aP] offset:%[oq]+" O "\n\t"
 #define LW "s_waitcnt lgkmcnt(0)\n\t"
-#define BUMP(N) "v_add_u32_e32 %[aP], " N ", %[aP]\n\tv_add_u32_e32 %[aQ], " N ", %[aQ]\n\tv_add_u32_e32 %[a0], " N ", %[a0]\n\tv_add_u32_e32 %[a1], " N ", %[a1]\n\tv_add_u32_e32 %[a2], " N ", %[a2]\n\t"
+#define BUMP(N) "v_add_u32_e32 %[aP], " N ", %[aP]\n\tv_add_u32_e32 %[a0], " N ", %[a0]\n\tv_add_u32_e32 %[a2], " N ", %[a2]\n\t"
 #define ZC(D, S) "v_cndmask_b32_e64 " D ", " S ", 0, %[nm]\n\t"
             asm volatile(
                 "s_cmp_eq_u32 %[nBall], 0\n\ts_cbranch_scc1 10f\n\t"
@@ -1419,7 +1430,7 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 "\n3:\n\ts_bitcmp1_b32 %[nB], 0\n\ts_cbranch_scc0 4f\n\t" SX1 SY1 F1A("32") F1Q("32") LW BUMP("32")
                 // B's last group with null items: the C operands of the null lanes are +0 for B's products only
                 "\n4:\n\ts_cmp_eq_u32 %[nBall], %[nB]\n\ts_cbranch_scc1 11f\n\t" SX1
-                ZC("v120", "v110") ZC("v121", "v111") ZC("v122", "v112") ZC("v123", "v113") ZC("v124", "v114") ZC("v125", "v115") SYP F1A("32") LW BUMP("32")
+                ZC("v112", "v102") ZC("v113", "v103") ZC("v114", "v104") ZC("v115", "v105") ZC("v116", "v106") ZC("v117", "v107") SYP F1A("32") LW BUMP("32")
                 "s_branch 11f\n"
                 "10:\n\ts_cmp_eq_u32 %[nA], 0\n\ts_cbranch_scc1 20f\n\t" F1A("0") LW
                 // ---- the rest of the run: the block's own value function only
@@ -1430,10 +1441,10 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 "\n14:\n\ts_bitcmp1_b32 %[nA], 0\n\ts_cbranch_scc0 20f\n\t" SX1
                 "\n20:\n\ts_nop 15\n\ts_nop 7"
                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [y0] "+v"(y0), [y1] "+v"(y1), [y2] "+v"(y2),
-                  [aP] "+v"(aP), [aQ] "+v"(aQ), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2_), [cnt] "=&s"(cnt)
-                : [nB] "s"(nBfull), [nBall] "s"(ngrpB), [nA] "s"(nAonly), [nm] "s"(nullmask)
-                : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124",
-                  "v125", "v126", "v127", "scc");
+                  [aP] "+v"(aP), [a0] "+v"(a0), [a2] "+v"(a2_), [cnt] "=&s"(cnt)
+                : [nB] "s"(nBfull), [nBall] "s"(ngrpB), [nA] "s"(nAonly), [nm] "s"(nullmask), [oq] "i"(36 * USX * 4), [o1] "i"(16 * USX * 4)
+                : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+                  "v117", "v118", "v119", "scc");
 #undef MF
 #undef SX1
 #undef SY1
@@ -1450,14 +1461,17 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
 #undef U2_LDS
             accU[0][0] = x0; accU[0][1] = x1; accU[0][2] = x2; accU[1][0] = y0; accU[1][1] = y1; accU[1][2] = y2;
         };
+        SCG_LITEU(1);                                            // (light stamps, variant 3) U2 starts
         for (int ch = 0; ch < nch; ++ch) {
-            if (ch > 0) block_lds_sync();                                     // previous chunk's operands consumed
+            if (ch > 0) { block_lds_sync(); SCG_LITEU(4); }                   // previous chunk's operands consumed
             SCG_STAMP(20);                                                    // (diagnostic) U2: MFMAs of the previous chunk + wait
             u2_build(ch, s_R, wave);
             SCG_STAMP(21);                                       // (diagnostic) U2: build
             block_lds_sync();                                    // operands visible
             SCG_STAMP(22);                                       // (diagnostic) U2: wait for the other waves' build
+            if (ch == 0) SCG_LITEU(2); else SCG_LITEU(5);
             u2_mfma(ch, s_R);
+            if (ch == 0) SCG_LITEU(3); else SCG_LITEU(6);
             SCG_STAMP(9);                                        // (diagnostic) U2: this wave's own products of the chunk
         }
         SCG_STAMP(pass == 0 ? 6 : 13);   // U2

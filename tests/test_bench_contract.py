@@ -34,7 +34,11 @@ def test_committed_bench_lines_carry_the_contract_fields():
         r = d["roofline"]
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0, name
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel_ms"] > 0, name
-        assert r["traffic"] is None or (r["traffic"] > 1e7 and "static" in r["traffic_source"]), name
+        # the source says whether this run measured it (two rocprofv3 counter passes run first) or read the tracked profile
+        assert r["traffic"] is None or (r["traffic"] > 1e7 and ("(static" in r["traffic_source"] or r["traffic_source"].startswith("measured by this run"))), name
+        if r["traffic"] is not None and r["traffic_source"].startswith("measured by this run"):
+            kb = r["traffic_counters_kb"]
+            assert r["traffic"] == int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024), name
         m = d["mfma"]
         assert m["bound"] == "mfma" and m["peak"] == 157.3 and 0.05 < m["frac"] < 1.0, name
         rk = d["ranks"]

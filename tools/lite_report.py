@@ -6,6 +6,7 @@ import argparse, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 ap = argparse.ArgumentParser(); ap.add_argument("--options", type=int, default=5); ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--u2", action="store_true", help="the library is the SCG_STAMPS_LITE=3 variant (make lite_u2): waves 12, 13, 0, 3 stamp inside U2 of pass 0")
 args = ap.parse_args()
 from skill_chaining_with_graphs_amd import _lib
 _lib.LIB_PATH = os.environ.get("SCG_LITE_LIB") or os.path.join(os.path.dirname(_lib.LIB_PATH), "libscg_hip_lite.so")
@@ -31,6 +32,18 @@ lib.scg_profile_read(ctx, C.byref(ms), C.byref(cnt))
 out = np.zeros((nblk, 48), np.uint64)
 lib.scg_diag_stamps(ctx, out.ctypes.data_as(C.c_void_p), 0)
 m = out[:, :32].astype(np.float64).mean(0).reshape(4, 8) / args.steps
+if args.u2:
+    names = ["whole kernel", "U2 starts (E barrier passed)", "chunk 0 built, barrier passed", "chunk 0: own products done", "chunk 0 consumed (barrier)", "chunk 1 built, barrier passed",
+             "chunk 1: own products done", "pass 0 done"]
+    print(f"{os.path.basename(_lib.LIB_PATH)}: fused kernel by HIP events {1e3 * ms.value / max(cnt.value, 1):.2f} us ({cnt.value} launches); cycles since kernel entry, mean over {nblk} blocks")
+    print(f"{'':32s} {'wave 12':>12s} {'wave 13':>12s} {'wave 0':>12s} {'wave 3':>12s}   (12, 13: the no-op's; blocks with one chunk leave 4-6 at 0: means are over all blocks)")
+    for i in [1, 2, 3, 4, 5, 6, 7, 0]:
+        print(f"{names[i]:32s} " + " ".join(f"{m[r, i]:12.0f}" for r in range(4)))
+    two = out[:, 6] > 0
+    mm = out[two][:, :32].astype(np.float64).mean(0).reshape(4, 8) / args.steps
+    print(f"blocks whose LAST launch had two chunks: {int(two.sum())} of {nblk}; own products of chunk 0 / chunk 1, cycles: " +
+          " | ".join(f"{mm[r, 3] - mm[r, 2]:.0f} / {mm[r, 6] - mm[r, 5]:.0f}" for r in range(4)))
+    sys.exit(0)
 names = ["whole kernel", "start barrier passed", "own phase-P work done", "phase-P barrier passed", "E starts", "own E done", "E barrier passed (U2 starts)", "pass 0 done"]
 print(f"{os.path.basename(_lib.LIB_PATH)}: fused kernel by HIP events {1e3 * ms.value / max(cnt.value, 1):.2f} us ({cnt.value} launches); cycles since kernel entry, mean over {nblk} blocks")
 print(f"{'':32s} {'env wave 0':>12s} {'pool wave':>12s} {'helper 0':>12s} {'last helper':>12s}")
