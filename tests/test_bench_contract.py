@@ -3,6 +3,7 @@ tools/ab_bench.py all parse these fields."""
 import glob
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -88,3 +89,21 @@ def test_round_4_lines_carry_the_extra_measurements():
         assert abs(dc["value"] - 65536 / (dc["us_per_step"] * 1e-6)) < 1e-3 * dc["value"], name
         seen += 1
     assert seen >= 2
+
+
+def test_live_traffic_never_starts_counter_passes_from_a_profiled_process(monkeypatch):
+    """bench.py measures roofline.traffic with two rocprofv3 child passes run before it touches the GPU. Under a profiler the
+    process has the GPU open from its first instruction (the tool's preloaded library): no child may be started from it —
+    the guard reads exactly the variables rocprofv3 7.2 sets for its child (checked in this image), and the line falls back
+    to the tracked static figure."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    def boom(*a, **k):
+        raise AssertionError("live_traffic started a child process from a profiled process")
+    monkeypatch.setattr(subprocess, "run", boom)
+    for var, val in (("ROCPROFILER_LIBRARY_CTOR", "1"), ("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"),
+                     ("ROCPROF_KERNEL_TRACE", "1"), ("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"), ("HSA_TOOLS_LIB", "libx.so")):
+        monkeypatch.setenv(var, val)
+        assert bench.live_traffic(65536, 5) is None, var
+        monkeypatch.delenv(var)
