@@ -99,7 +99,10 @@ def live_traffic(envs_per_gpu, n_options, timeout_s=150):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or os.environ.get("HSA_TOOLS_LIB") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None                                  # this run is itself being profiled: its process has the GPU open already
     raw = {}
-    tmp = tempfile.mkdtemp(prefix="scg_traffic_", dir="/tmp")
+    try:
+        tmp = tempfile.mkdtemp(prefix="scg_traffic_", dir="/tmp")
+    except OSError:
+        return None
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
