@@ -253,7 +253,11 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
     int *s_misc = reinterpret_cast<int *>(smem + OFF_MISC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SCG_DIAG_ROTATE          // (diagnostic: workgroup p works on block (p + SCG_DIAG_ROTATE) % grid — same results; do the slow blocks follow the DATA or the PLACE? tools/straggler_report.py)
+    const int b = (int)((blockIdx.x + SCG_DIAG_ROTATE) % gridDim.x);
+#else
     const int b = blockIdx.x;
+#endif
     const int e0 = b * BLOCK_ENVS;
     const int nb = min(BLOCK_ENVS, A.n - e0);
     const int N = A.n;
