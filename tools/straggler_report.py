@@ -8,6 +8,7 @@ sys.path[:0] = [ROOT]
 ap = argparse.ArgumentParser(); ap.add_argument("--launches", type=int, default=24)
 ap.add_argument("--rotate", type=int, default=0, help="the library was built with -DSCG_DIAG_ROTATE=R (make lite_rot: 100): workgroup p holds block (p + R) %% grid")
 ap.add_argument("--pad-kb", type=int, default=0, help="allocate this much device memory BEFORE the agent's buffers (moves every buffer: does the slow set follow the addresses?)")
+ap.add_argument("--p-internal", action="store_true", help="the library is the SCG_STAMPS_LITE=2 build (make lite_p): env wave 0's boundaries lie INSIDE phase P")
 ap.add_argument("--options", type=int, default=5); ap.add_argument("--seed", type=int, default=1000)
 args = ap.parse_args()
 from skill_chaining_with_graphs_amd import _lib
@@ -88,6 +89,18 @@ print("the slowest block of each launch:", slow_each.tolist())
 
 tk = np.concatenate(ticks, 0); t0 = np.concatenate(t0s, 0)
 seg = np.stack([tk[:, 3], tk[:, 4] - tk[:, 3], tk[:, 6] - tk[:, 4], tk[:, 7] - tk[:, 6], tk[:, 0] - tk[:, 7]], 1)
+if args.p_internal:
+    slow = d >= np.percentile(d, 97); rest = d <= np.percentile(d, 60)
+    names = ["entry state gathered + published", "action chosen + published", "own physics done, pair groups listed", "pooled pair groups done, results read back", "result line written",
+             "trace, events, histogram issued", "phase-P barrier passed"]
+    print(f"phase P of env wave 0 (s_memtime since entry), slowest 3 % of the blocks ({int(slow.sum())}) against the lower 60 % ({int(rest.sum())}): wall {d[slow].mean():.2f} / {d[rest].mean():.2f} us")
+    prev_s = prev_r = 0.0
+    for i, nm in enumerate(names, 1):
+        a, b_ = tk[slow, i].mean(), tk[rest, i].mean()
+        print(f"  {nm:44s} {a:9.0f} {b_:9.0f}   step {a - prev_s:7.0f} {b_ - prev_r:7.0f}  {(a - prev_s) - (b_ - prev_r):+7.0f}")
+        prev_s, prev_r = a, b_
+    print(f"  {'whole kernel':44s} {tk[slow, 0].mean():9.0f} {tk[rest, 0].mean():9.0f}")
+    sys.exit(0)
 lab = ["head (-> P barrier)", "Z + lists", "E (-> barrier)", "U2", "tail"]
 slow = d >= np.percentile(d, 97); rest = d <= np.percentile(d, 60)
 print(f"same launches, env wave 0's s_memtime ticks: slowest 3 % of the blocks ({int(slow.sum())}) against the lower 60 % ({int(rest.sum())})")
