@@ -691,6 +691,12 @@ __global__ __launch_bounds__(THREADS, 4) void td_kernel(const StepArgs A) {
                 gsum[0] = 0;
 #pragma unroll
                 for (int w2 = 0; w2 < P_WAVES; ++w2) gsum[w2 + 1] = gsum[w2] + s_misc[M_GROUPS + w2];
+#ifdef SCG_STAMPS_LITE
+                if (A.stamps && wave == 0 && lane == 0) A.stamps[(size_t)blockIdx.x * STAMP_SLOTS + 42] = (unsigned long long)gsum[P_WAVES];      // slot 42: the block's pair groups (last launch)
+#endif
+                // (a block has 5-7 groups as a rule and 8 in 3 % of the cases: a second round on wave 0 — those blocks are 72 % of the launches'
+                //  slowest workgroups; handing the groups beyond the first round to two helper waves was built, bit-exact, and did not pay:
+                //  profiles/r05_stragglers.txt, profiles/r05_pair_group_overflow.diff)
                 for (int q = wave; q < gsum[P_WAVES]; q += P_POOL) {
                     int owner = 0, first = 0;
 #pragma unroll

@@ -28,7 +28,7 @@ lib, ctx = agent.ctx.lib, agent.ctx._ctx
 lib.scg_diag_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 B = lib.scg_block_envs(); nblk = n // B
 lib.scg_diag_stamps(ctx, None, 1)
-rows = []; ticks = []; t0s = []; extra = []
+rows = []; ticks = []; t0s = []; extra = []; groups = []
 for it in range(args.launches):
     for _ in range(3): agent.step_batch()
     torch.cuda.synchronize()
@@ -41,6 +41,7 @@ for it in range(args.launches):
     if args.rotate:                                        # stamps are stored per WORKGROUP: re-index them by the block the workgroup held
         out = out[(np.arange(nblk) - args.rotate) % nblk]
     dur = (out[:, 33].astype(np.int64) - out[:, 32].astype(np.int64)) / 100.0
+    groups.append(out[:, 42].astype(np.float64))
     ticks.append(out[:, :8].astype(np.float64))           # env wave 0: [0] whole kernel, [1..7] the phase boundaries (s_memtime since entry)
     t0s.append((out[:, 32].astype(np.int64) - out[:, 32].astype(np.int64).min()) / 100.0)
     key = np.where(opt > 0, opt, 0)
@@ -88,6 +89,12 @@ slow_each = per.argmax(1)
 print("the slowest block of each launch:", slow_each.tolist())
 
 tk = np.concatenate(ticks, 0); t0 = np.concatenate(t0s, 0)
+G = np.concatenate(groups, 0)
+print("pair groups of the block's physics (64 (env, edge) pairs each; seven waves take one each per round) -> blocks, mean wall us, share of the per-launch maxima:")
+is_max = np.zeros(len(d), bool); is_max[np.arange(args.launches) * nblk + per.argmax(1)] = True
+for gv in np.unique(G):
+    m = G == gv
+    print(f"   {int(gv):3d} groups: {int(m.sum()):6d} blocks  {d[m].mean():6.2f} us   {is_max[m].sum() / args.launches:5.2f}")
 seg = np.stack([tk[:, 3], tk[:, 4] - tk[:, 3], tk[:, 6] - tk[:, 4], tk[:, 7] - tk[:, 6], tk[:, 0] - tk[:, 7]], 1)
 if args.p_internal:
     slow = d >= np.percentile(d, 97); rest = d <= np.percentile(d, 60)
