@@ -28,6 +28,38 @@ lib, ctx = agent.ctx.lib, agent.ctx._ctx
 lib.scg_diag_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 B = lib.scg_block_envs(); nblk = n // B
 lib.scg_diag_stamps(ctx, None, 1)
+def env_order(key):
+    """SPEC §5's CHUNKED layout restated on the host (csrc/scg_kernels.hip order_layout / order_posk / order_pos0): every block starts with at most c envs of
+    ONE option's run and is filled with root-keyed envs behind them; ranks inside a key are by env id. Returns order[pos] = env."""
+    nk = 7
+    tot = np.bincount(key, minlength=nk)
+    S, Rn, Bf = int(tot[1:].sum()), int((tot[1:] > 0).sum()), n // B
+    c = B
+    if Bf > Rn and S > 0: c = min(B, -(-S // (Bf - Rn)))
+    g = B - c
+    cnt = np.zeros(nk, int); start = np.zeros(nk, int); F = np.zeros(nk, int)
+    U = Fs = 0
+    for k in range(1, nk):
+        cnt[k] = -(-int(tot[k]) // c); start[k] = U * B; F[k] = Fs
+        U += cnt[k]; Fs += cnt[k] * B - int(tot[k])
+    assert U * B <= n, "padded layout: not restated here"
+    pos = np.empty(n, np.int64)
+    for k in range(1, nk):
+        e = np.nonzero(key == k)[0]; r = np.arange(len(e)); t = r // c
+        pos[e] = start[k] + B * t + (r - t * c)
+    e0 = np.nonzero(key == 0)[0]; r = np.arange(len(e0))
+    p0 = U * B + (r - Fs)
+    for k in range(1, nk):
+        fills = cnt[k] * B - int(tot[k])
+        m = (r >= F[k]) & (r < F[k] + fills)
+        rp = r[m] - F[k]; nfull = cnt[k] - 1
+        a = np.where((g > 0) & (rp < nfull * g), start[k] + B * (rp // max(g, 1)) + c + (rp % max(g, 1)),
+                     start[k] + B * nfull + (int(tot[k]) - nfull * c) + (rp - nfull * g))
+        p0[m] = a
+    pos[e0] = p0
+    order = np.empty(n, np.int64); order[pos] = np.arange(n)
+    assert (np.sort(pos) == np.arange(n)).all()
+    return order
 rows = []; ticks = []; t0s = []; extra = []; groups = []
 for it in range(args.launches):
     for _ in range(3): agent.step_batch()
@@ -45,7 +77,7 @@ for it in range(args.launches):
     ticks.append(out[:, :8].astype(np.float64))           # env wave 0: [0] whole kernel, [1..7] the phase boundaries (s_memtime since entry)
     t0s.append((out[:, 32].astype(np.int64) - out[:, 32].astype(np.int64).min()) / 100.0)
     key = np.where(opt > 0, opt, 0)
-    order = np.argsort(key, kind="stable")
+    order = env_order(key)
     if it == args.launches - 1:                            # what the blocks of the last launch held, by position in the env order
         st = agent.state
         opt_after = st.option_id.cpu().numpy().astype(np.int64)
@@ -73,15 +105,9 @@ print(f"per launch: mean of block means {per.mean(1).mean():.2f} us, mean of blo
 def grp(name, m):
     if m.sum(): print(f"  {name:58s} {int(m.sum()):6d} blocks  mean {d[m].mean():6.2f}  p90 {np.percentile(d[m], 90):6.2f}  max {d[m].max():6.2f}")
 inopt, stay, nk = r[:, 1], r[:, 2], r[:, 3]
-grp("root only, nobody staying out", (inopt == 0) & (stay == 0))
-for lo, hi in ((1, 16), (16, 64), (64, 128), (128, 257)):
-    grp(f"root only, {lo}..{hi - 1} envs staying out of an option", (inopt == 0) & (stay >= lo) & (stay < hi))
-grp("one option's envs only (all 256 run it)", (inopt == B) & (nk == 1))
-grp("mixed: root + one option", (inopt > 0) & (inopt < B) & (nk == 2))
-grp("mixed: two options or more (+ root)", nk >= 3)
-for kk in range(1, nopt + 1):
-    grp(f"blocks whose option is {kk} (any mix)", (r[:, 4] == kk))
-print("distinct options among the staying-out envs of root-only blocks -> mean us:", " ".join(f"{int(v)}: {d[(inopt == 0) & (r[:, 5] == v)].mean():.2f}" for v in np.unique(r[(inopt == 0), 5])))
+for kk in range(0, nopt + 1):
+    grp(f"blocks that start with option {kk}'s envs" if kk else "blocks of root-keyed envs only", (r[:, 4] == kk))
+print("envs of the block's option per block: mean %.1f, max %d" % (inopt.mean(), inopt.max()))
 top = np.argsort(d)[-16:][::-1]
 print("slowest 16 (us, envs in an option, staying out, keys in block, option, launch, block):")
 for i in top: print(f"   {d[i]:6.2f}  {int(r[i,1]):4d} {int(r[i,2]):4d} {int(r[i,3]):2d} {int(r[i,4]):2d}   launch {int(r[i,7]):2d} block {int(r[i,6]):3d}")
@@ -91,6 +117,10 @@ print("the slowest block of each launch:", slow_each.tolist())
 tk = np.concatenate(ticks, 0); t0 = np.concatenate(t0s, 0)
 G = np.concatenate(groups, 0)
 print("pair groups of the block's physics (64 (env, edge) pairs each; seven waves take one each per round) -> blocks, mean wall us, share of the per-launch maxima:")
+Gb = G.reshape(args.launches, nblk)
+print("mean pair groups by position in the env order (16 bins of 16 blocks):", " ".join(f"{v:.2f}" for v in Gb.mean(0).reshape(16, -1).mean(1)))
+print("share of launches with 8 groups or more, blocks 20..47:", " ".join(f"{(Gb[:, b] >= 8).mean():.2f}" for b in range(20, 48)))
+print("... and over all blocks: mean %.3f; blocks where it is above 0.15: %s" % ((Gb >= 8).mean(), [int(b) for b in np.nonzero((Gb >= 8).mean(0) > 0.15)[0]]))
 is_max = np.zeros(len(d), bool); is_max[np.arange(args.launches) * nblk + per.argmax(1)] = True
 for gv in np.unique(G):
     m = G == gv
